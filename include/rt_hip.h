@@ -1,0 +1,215 @@
+/*
+ * rt_hip.h — C ABI of the MI355X (gfx950) render-loop library.
+ *
+ * The library replaces the body of the host's per-pixel CPU loop
+ *     Raytracer.Render()                        /root/reference/MyApplication.cs:402-426
+ * and everything that loop calls (GetRayDirection :428-452, Scene.Intersect /
+ * IsInShadow :352-380, Primitive.Shade objects.cs:44-96, the Sphere / Plane /
+ * Triangle Intersect routines objects.cs:109-273, checkerboard and texture lookup
+ * objects.cs:176-213,348-353, MixColor objects.cs:35-41).  The host keeps its
+ * window, camera controls, scene construction and present path; it hands the
+ * library a flattened scene once and a camera per frame, and receives the
+ * 0x00RRGGBB framebuffer that Surface.pixels (surface.cs:9-19) holds.
+ *
+ * Conventions
+ *   - blittable types only: plain pointers, 32-bit ints and floats, no C++ types;
+ *   - every call returns RT_OK (0) or a negative rt_status; no exception and no
+ *     abort crosses the boundary; rt_last_error() returns the message the host
+ *     would put into `throw new Exception(msg)` (the reference's only error
+ *     convention, template.cs:102-106);
+ *   - the caller owns every host pointer it passes; the library copies inside the
+ *     call and never retains the pointer;
+ *   - one caller thread per context (the reference renders from the single window
+ *     thread, template.cs:185-204); contexts are independent of each other.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_API_VERSION 1
+
+/* Primitive type codes — the reference's own flatten uses exactly these
+ * (MyApplication.cs:161,166,173). */
+#define RT_PRIM_SPHERE   0
+#define RT_PRIM_PLANE    1
+#define RT_PRIM_TRIANGLE 2
+
+/* The reference hard-codes `depth < 5` (objects.cs:84). */
+#define RT_REFERENCE_MAX_DEPTH 5
+/* Upper bound the library accepts for max_depth (levels 0..RT_MAX_DEPTH). */
+#define RT_MAX_DEPTH 16
+#define RT_MAX_TEXTURES 8
+
+typedef enum rt_status {
+    RT_OK                 =  0,
+    RT_ERR_INVALID_ARG    = -1,  /* NULL pointer, bad size, bad type code ...            */
+    RT_ERR_NO_DEVICE      = -2,  /* no usable gfx950 device / bad device id             */
+    RT_ERR_OUT_OF_MEMORY  = -3,  /* host or device allocation failed                    */
+    RT_ERR_HIP            = -4,  /* a HIP runtime call failed (message has the detail)  */
+    RT_ERR_NO_SCENE       = -5,  /* rt_render before rt_set_scene                        */
+    RT_ERR_BAD_TEXTURE    = -6,  /* a primitive names a texture slot that is not loaded */
+    RT_ERR_LIMIT          = -7   /* request exceeds a fixed limit of an entry point     */
+} rt_status;
+
+/* Camera fields read by the render loop (MyApplication.cs:259-275: position,
+ * direction, up, fov in degrees).  Three consecutive floats = OpenTK Vector3. */
+typedef struct rt_camera {
+    float position[3];
+    float direction[3];
+    float up[3];
+    float fov_deg;
+} rt_camera;
+
+/*
+ * Flattened scene, structure of arrays.  Field-for-field the arrays the reference
+ * builds in MyApplication.Init (MyApplication.cs:142-176), with two changes: the
+ * capacity is dynamic (the reference fixes it at 10, :48-62) and a per-primitive
+ * texture slot is added (the reference keeps the texture on the Plane object,
+ * objects.cs:146, and never flattens it).
+ *
+ * Primitive i is described by the i-th element of every prim_* array; order is the
+ * host's insertion order and decides ties in closest-hit (lowest index wins,
+ * MyApplication.cs:361).  Arrays that do not apply to a primitive's type are
+ * ignored for that primitive but must still be addressable.
+ */
+typedef struct rt_scene {
+    int32_t num_prims;
+    int32_t num_lights;
+    const int32_t *prim_types;        /* [n]   RT_PRIM_*                                        */
+    const float   *prim_positions;    /* [3n]  sphere centre                                    */
+    const float   *prim_normals;      /* [3n]  plane / triangle unit normal as the host's
+                                               constructors computed it (objects.cs:150,233)    */
+    const float   *prim_diffuse;      /* [4n]  Material.diffuseColor RGBA                       */
+    const float   *prim_glossy;       /* [4n]  Material.glossyColor                             */
+    const float   *prim_ambient;      /* [4n]  Material.ambientColor                            */
+    const float   *prim_specular;     /* [n]   Material.specular                                */
+    const float   *prim_radius;       /* [n]   Sphere.radius                                    */
+    const float   *prim_d;            /* [n]   Plane.d (plane: n.p + d = 0)                     */
+    const float   *prim_v0;           /* [3n]  Triangle vertices                                */
+    const float   *prim_v1;           /* [3n]                                                   */
+    const float   *prim_v2;           /* [3n]                                                   */
+    const int32_t *prim_checkerboard; /* [n]   Material.useCheckerboard as 0/1                  */
+    const int32_t *prim_texture;      /* [n]   texture slot (planes only) or -1; NULL = all -1  */
+    const float   *light_positions;   /* [3L]  Light.position                                   */
+    const float   *light_colors;      /* [4L]  Light.color (reference: 2,2,2,1)                 */
+} rt_scene;
+
+/* Ray / work accounting of the last rt_render* call on the context.
+ *   primary    one per pixel                                   (MyApplication.cs:415)
+ *   shadow     one per shaded hit and light                    (objects.cs:56)
+ *   secondary  one per shaded hit with specular != 0 at a level below max_depth —
+ *              the reflection trace whose result is used, counted once per level
+ *              (objects.cs:83; the reference repeats it once per light)
+ * sphere/plane/triangle_tests count the Intersect calls the reference's algorithm makes
+ * (an occluded light ray stops at its first occluder in primitive order,
+ * MyApplication.cs:373-378), whatever the kernels actually evaluate.
+ * Times are milliseconds of the last call, measured with HIP events on the stream the
+ * kernels ran on and only while profiling is enabled (rt_set_profiling): kernel_ms spans
+ * the whole frame pipeline; primary_ms, trace_ms and shade_ms split it into the primary
+ * kernel, the per-level ray traversal kernels and the per-level shading kernels.  With
+ * several devices each is the maximum over the devices. */
+typedef struct rt_stats {
+    uint64_t rays_primary;
+    uint64_t rays_shadow;
+    uint64_t rays_secondary;
+    uint64_t shaded_hits;
+    uint64_t sphere_tests;
+    uint64_t plane_tests;
+    uint64_t triangle_tests;
+    double   kernel_ms;
+    double   primary_ms;
+    double   trace_ms;
+    double   shade_ms;
+    double   gather_ms;       /* rt_render with several devices: blocks -> first device */
+    double   copy_ms;         /* rt_render: device -> pixels_out                        */
+    int32_t  num_devices;
+    int32_t  reserved;
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Library / ABI version (RT_API_VERSION of the build). */
+int rt_api_version(void);
+
+/* Number of HIP devices visible to the process, or a negative rt_status. */
+int rt_device_count(void);
+
+/*
+ * Create a context on the given devices (device_ids == NULL or n_devices <= 0:
+ * device 0 only).  With more than one device, rt_render() splits the frame into
+ * contiguous row blocks, one per device — the image-space partition the reference
+ * already uses for its thread pool (Parallel.For over rows, MyApplication.cs:408)
+ * — and gathers the blocks on the first device.
+ * Replaces: the Raytracer constructor (MyApplication.cs:392-400).
+ */
+int rt_create(rt_ctx **out, const int *device_ids, int n_devices);
+
+/* Free every device and host resource of the context.  NULL is ignored. */
+void rt_destroy(rt_ctx *ctx);
+
+/* Message of the last failing call on ctx; with ctx == NULL, of the last failing
+ * rt_create on this thread.  Never NULL; valid until the next call on ctx. */
+const char *rt_last_error(const rt_ctx *ctx);
+
+/*
+ * Copy the flattened scene to every device of the context.
+ * Replaces: Scene.primitives / Scene.lights as read by the loop
+ * (MyApplication.cs:341-350) — call once after the host's Init() (template.cs:155)
+ * and again whenever the host edits the scene.
+ */
+int rt_set_scene(rt_ctx *ctx, const rt_scene *scene);
+
+/*
+ * Load an RGBA8 image (row-major, row 0 first, 4 bytes per texel in R,G,B,A order)
+ * into a texture slot.  Replaces: Texture.LoadTexture (objects.cs:331-346), which
+ * stores Bitmap.GetPixel(x,y) as R/255f.. in pixels[x,y]; lookups are point
+ * samples with the address arithmetic of Plane.GetTextureCoordinates and
+ * Texture.GetColor (objects.cs:190-204,348-353).
+ */
+int rt_set_texture(rt_ctx *ctx, int slot, const uint8_t *rgba8, int width, int height);
+
+/*
+ * Render one frame of width x height pixels into pixels_out (host memory,
+ * width*height int32, row-major, row 0 = top of the window, value 0x00RRGGBB,
+ * 0 where the primary ray hits nothing).  Blocking: every element is written
+ * before the call returns.  max_depth bounds the mirror recursion exactly like the
+ * literal 5 in `depth < 5` (objects.cs:84); pass RT_REFERENCE_MAX_DEPTH for the
+ * reference's behaviour.
+ * Replaces: Raytracer.Render() (MyApplication.cs:402-426).
+ */
+int rt_render(rt_ctx *ctx, const rt_camera *camera, int width, int height,
+              int max_depth, int32_t *pixels_out);
+
+/*
+ * Render rows [row_begin, row_end) of a width x height frame on the context's
+ * first device into device memory: dev_pixels_out points to (row_end-row_begin) *
+ * width int32 on that device; element (y - row_begin) * width + x is pixel (x, y)
+ * of the full frame.  The work is enqueued on hip_stream (a hipStream_t; NULL =
+ * the default stream) and the call returns without synchronising; per-frame
+ * scratch is owned by the context, so calls on one context must not overlap.
+ * This is the per-rank entry of the one-process-per-GPU row partition: rank r of
+ * G renders its block and the framebuffer blocks are gathered with one
+ * collective.  It is also Render() for hosts that present straight from device
+ * memory.  Same semantics per pixel as rt_render (MyApplication.cs:410-424).
+ */
+int rt_render_rows_device(rt_ctx *ctx, const rt_camera *camera, int width, int height,
+                          int row_begin, int row_end, int max_depth,
+                          int32_t *dev_pixels_out, void *hip_stream);
+
+/* Counters and timings of the last render call.  Synchronises the context's
+ * devices (needed to read the device-side counters). */
+int rt_get_stats(rt_ctx *ctx, rt_stats *out);
+
+/* Enable (1) or disable (0) device-side ray/test counters and event timing for
+ * later render calls on the context.  Off by default: the counters cost atomics. */
+int rt_set_profiling(rt_ctx *ctx, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -1,0 +1,158 @@
+"""ctypes view of include/rt_hip.h and the loader of librt_hip.so.
+
+The structs mirror the header field for field.  The loader fails loudly when the
+HIP library has not been built: there is no CPU fallback behind this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+RT_PRIM_SPHERE = 0
+RT_PRIM_PLANE = 1
+RT_PRIM_TRIANGLE = 2
+RT_REFERENCE_MAX_DEPTH = 5
+RT_MAX_DEPTH = 16
+RT_MAX_TEXTURES = 8
+
+RT_OK = 0
+STATUS_NAMES = {
+    0: "RT_OK",
+    -1: "RT_ERR_INVALID_ARG",
+    -2: "RT_ERR_NO_DEVICE",
+    -3: "RT_ERR_OUT_OF_MEMORY",
+    -4: "RT_ERR_HIP",
+    -5: "RT_ERR_NO_SCENE",
+    -6: "RT_ERR_BAD_TEXTURE",
+    -7: "RT_ERR_LIMIT",
+}
+
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int32)
+
+
+class rt_camera(C.Structure):
+    _fields_ = [
+        ("position", C.c_float * 3),
+        ("direction", C.c_float * 3),
+        ("up", C.c_float * 3),
+        ("fov_deg", C.c_float),
+    ]
+
+
+class rt_scene(C.Structure):
+    _fields_ = [
+        ("num_prims", C.c_int32),
+        ("num_lights", C.c_int32),
+        ("prim_types", _i),
+        ("prim_positions", _f),
+        ("prim_normals", _f),
+        ("prim_diffuse", _f),
+        ("prim_glossy", _f),
+        ("prim_ambient", _f),
+        ("prim_specular", _f),
+        ("prim_radius", _f),
+        ("prim_d", _f),
+        ("prim_v0", _f),
+        ("prim_v1", _f),
+        ("prim_v2", _f),
+        ("prim_checkerboard", _i),
+        ("prim_texture", _i),
+        ("light_positions", _f),
+        ("light_colors", _f),
+    ]
+
+
+class rt_stats(C.Structure):
+    _fields_ = [
+        ("rays_primary", C.c_uint64),
+        ("rays_shadow", C.c_uint64),
+        ("rays_secondary", C.c_uint64),
+        ("shaded_hits", C.c_uint64),
+        ("sphere_tests", C.c_uint64),
+        ("plane_tests", C.c_uint64),
+        ("triangle_tests", C.c_uint64),
+        ("kernel_ms", C.c_double),
+        ("primary_ms", C.c_double),
+        ("trace_ms", C.c_double),
+        ("shade_ms", C.c_double),
+        ("gather_ms", C.c_double),
+        ("copy_ms", C.c_double),
+        ("num_devices", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+# Every symbol include/rt_hip.h declares: name -> (restype, argtypes).
+EXPORTS = {
+    "rt_api_version": (C.c_int, []),
+    "rt_device_count": (C.c_int, []),
+    "rt_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]),
+    "rt_destroy": (None, [C.c_void_p]),
+    "rt_last_error": (C.c_char_p, [C.c_void_p]),
+    "rt_set_scene": (C.c_int, [C.c_void_p, C.POINTER(rt_scene)]),
+    "rt_set_texture": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "rt_render": (
+        C.c_int,
+        [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
+    "rt_render_rows_device": (
+        C.c_int,
+        [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+         C.c_void_p, C.c_void_p],
+    ),
+    "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(rt_stats)]),
+    "rt_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+}
+
+LIB_NAME = "librt_hip.so"
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
+
+
+_lib = None
+
+
+def _preload_torch_hip_runtime() -> None:
+    """Keep ONE HIP runtime in the process.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as the system one).
+    If librt_hip.so pulled in /opt/rocm's copy first and torch loaded its own afterwards,
+    the process would hold two HIP/HSA runtimes and the second finds no GPU.  Loading
+    torch's copy (when torch is installed; torch itself is not imported) before
+    librt_hip.so makes the dynamic loader resolve both to the same runtime.  Hosts
+    without torch (the C# application) simply use the system runtime.
+    """
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+def load_library() -> C.CDLL:
+    """Load librt_hip.so and bind every exported symbol.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build the HIP library first "
+            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
+        )
+    _preload_torch_hip_runtime()
+    lib = C.CDLL(path)
+    for name, (restype, argtypes) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib

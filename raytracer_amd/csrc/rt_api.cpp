@@ -1,0 +1,664 @@
+// rt_api.cpp — host side of librt_hip.so: contexts, scene packing, per-frame camera
+// constants, the frame pipeline and the C ABI of include/rt_hip.h.
+//
+// Built with -ffp-contract=off: the few FP32 values computed here (camera constants,
+// r*r, triangle edges) follow the reference's operation order like the kernels do.
+#include "../../include/rt_hip.h"
+#include "rt_device.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DeviceState {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {};  // begin, after primary, after trace, after shade, after gather copy
+    int num_cus = 256;
+
+    // scene
+    DevScene scene{};
+    std::vector<void *> scene_allocs;
+    float4 *sph_cam = nullptr;
+    void *tex_mem[RT_MAX_TEXTURES] = {};
+
+    // per-frame scratch
+    DevFrame frame{};
+    size_t cap_slots = 0, cap_mask = 0;
+    int cap_levels = 0;
+    int32_t *out = nullptr;  // device framebuffer block of this device
+    size_t cap_out = 0;
+
+    // last call
+    int last_P = 0, last_depth = 0;
+    bool timed = false;
+};
+
+}  // namespace
+
+struct rt_ctx {
+    std::vector<DeviceState> dev;
+    std::string error;
+    bool have_scene = false;
+    bool profiling = false;
+    int num_prims = 0, num_lights = 0, ns = 0, np = 0, nt = 0;
+    uint32_t textures_used = 0;    // bit i: some primitive names texture slot i
+    uint32_t textures_loaded = 0;  // bit i: slot i holds an image
+    int32_t *staging = nullptr;    // pinned host staging for rt_render
+    size_t cap_staging = 0;
+    double copy_ms = 0.0, gather_ms = 0.0;
+    std::vector<int> last_rows;    // row split of the last rt_render (n_dev + 1 entries)
+    int last_w = 0, last_h = 0;
+    bool last_was_rows_device = false;
+};
+
+namespace {
+
+int fail(rt_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                     \
+    } while (0)
+
+void free_scene(DeviceState &d)
+{
+    for (void *p : d.scene_allocs) (void)hipFree(p);
+    d.scene_allocs.clear();
+    if (d.sph_cam) (void)hipFree(d.sph_cam);
+    d.sph_cam = nullptr;
+    const uchar4 *tex[RT_DEV_MAX_TEXTURES];
+    int tw[RT_DEV_MAX_TEXTURES], th[RT_DEV_MAX_TEXTURES];
+    memcpy(tex, d.scene.tex, sizeof tex);
+    memcpy(tw, d.scene.tex_w, sizeof tw);
+    memcpy(th, d.scene.tex_h, sizeof th);
+    d.scene = DevScene{};
+    memcpy(d.scene.tex, tex, sizeof tex);  // textures outlive the scene
+    memcpy(d.scene.tex_w, tw, sizeof tw);
+    memcpy(d.scene.tex_h, th, sizeof th);
+}
+
+void free_frame(DeviceState &d)
+{
+    if (d.frame.recA) (void)hipFree(d.frame.recA);
+    if (d.frame.recB) (void)hipFree(d.frame.recB);
+    if (d.frame.refl) (void)hipFree(d.frame.refl);
+    if (d.frame.mask) (void)hipFree(d.frame.mask);
+    if (d.frame.cnt) (void)hipFree(d.frame.cnt);
+    if (d.frame.counters) (void)hipFree(d.frame.counters);
+    if (d.out) (void)hipFree(d.out);
+    d.frame = DevFrame{};
+    d.out = nullptr;
+    d.cap_slots = d.cap_mask = d.cap_out = 0;
+    d.cap_levels = 0;
+}
+
+template <typename T>
+int upload(rt_ctx *ctx, DeviceState &d, const std::vector<T> &host, const T **dev_out)
+{
+    // Never a zero-byte allocation: kernels index element 0 only when a count says so,
+    // but a non-null pointer keeps every launch argument well formed.
+    size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
+    void *p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, bytes));
+    d.scene_allocs.push_back(p);
+    if (!host.empty())
+        HIP_TRY(ctx, hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev_out = static_cast<const T *>(p);
+    return RT_OK;
+}
+
+struct PackedScene {
+    std::vector<float4> sph, pl, tri, geo, mat, light_pos, light_col;
+    std::vector<int> sph_orig, pl_orig, tri_orig, class_prefix;
+    uint32_t textures_used = 0;
+};
+
+int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
+{
+    const int n = s->num_prims, nl = s->num_lights;
+    out.geo.resize(n);
+    out.mat.resize(3 * (size_t)n);
+    out.class_prefix.assign(3 * ((size_t)n + 1), 0);
+    int cs = 0, cp = 0, ct = 0;
+    for (int i = 0; i < n; i++) {
+        const int type = s->prim_types[i];
+        if (type < RT_PRIM_SPHERE || type > RT_PRIM_TRIANGLE)
+            return fail(ctx, RT_ERR_INVALID_ARG, "prim_types[%d] = %d is not a primitive type", i, type);
+        out.class_prefix[3 * (size_t)i + 0] = cs;
+        out.class_prefix[3 * (size_t)i + 1] = cp;
+        out.class_prefix[3 * (size_t)i + 2] = ct;
+        int flags = type;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (type == RT_PRIM_SPHERE) {
+            const float *p = s->prim_positions + 3 * (size_t)i;
+            const float r = s->prim_radius[i];
+            out.sph.push_back(make_float4(p[0], p[1], p[2], r * r));  // objects.cs:114 radius*radius
+            out.sph_orig.push_back(i);
+            g = make_float4(p[0], p[1], p[2], 0.f);
+            cs++;
+        } else if (type == RT_PRIM_PLANE) {
+            const float *nn = s->prim_normals + 3 * (size_t)i;
+            out.pl.push_back(make_float4(nn[0], nn[1], nn[2], s->prim_d[i]));
+            out.pl_orig.push_back(i);
+            g = make_float4(nn[0], nn[1], nn[2], 0.f);
+            if (s->prim_checkerboard[i]) flags |= RT_MF_CHECKER;
+            const int tex = s->prim_texture ? s->prim_texture[i] : -1;
+            if (tex >= RT_MAX_TEXTURES)
+                return fail(ctx, RT_ERR_INVALID_ARG, "prim_texture[%d] = %d exceeds %d slots", i, tex,
+                            RT_MAX_TEXTURES);
+            if (tex >= 0) {
+                flags |= (tex + 1) << RT_MF_TEX_SHIFT;
+                out.textures_used |= 1u << tex;
+            }
+            cp++;
+        } else {
+            const float *v0 = s->prim_v0 + 3 * (size_t)i, *v1 = s->prim_v1 + 3 * (size_t)i,
+                        *v2 = s->prim_v2 + 3 * (size_t)i;
+            const float *nn = s->prim_normals + 3 * (size_t)i;
+            out.tri.push_back(make_float4(v0[0], v0[1], v0[2], 0.f));
+            out.tri.push_back(make_float4(v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], 0.f));  // e1
+            out.tri.push_back(make_float4(v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.f));  // e2
+            out.tri_orig.push_back(i);
+            g = make_float4(nn[0], nn[1], nn[2], 0.f);
+            ct++;
+        }
+        out.geo[i] = g;
+        const float *dc = s->prim_diffuse + 4 * (size_t)i, *gc = s->prim_glossy + 4 * (size_t)i,
+                    *ac = s->prim_ambient + 4 * (size_t)i;
+        float flags_as_float;
+        memcpy(&flags_as_float, &flags, sizeof flags);
+        out.mat[3 * (size_t)i + 0] = make_float4(dc[0], dc[1], dc[2], s->prim_specular[i]);
+        out.mat[3 * (size_t)i + 1] = make_float4(gc[0], gc[1], gc[2], flags_as_float);
+        out.mat[3 * (size_t)i + 2] = make_float4(ac[0], ac[1], ac[2], 0.f);
+    }
+    while (out.sph.size() % RT_SPH_PAD != 0) {
+        out.sph.push_back(make_float4(0.f, 0.f, 0.f, -INFINITY));
+        out.sph_orig.push_back(INT32_MAX);
+    }
+    out.class_prefix[3 * (size_t)n + 0] = cs;
+    out.class_prefix[3 * (size_t)n + 1] = cp;
+    out.class_prefix[3 * (size_t)n + 2] = ct;
+    out.light_pos.resize(nl);
+    out.light_col.resize(nl);
+    for (int l = 0; l < nl; l++) {
+        const float *p = s->light_positions + 3 * (size_t)l, *c = s->light_colors + 4 * (size_t)l;
+        out.light_pos[l] = make_float4(p[0], p[1], p[2], 0.f);
+        out.light_col[l] = make_float4(c[0], c[1], c[2], c[3]);
+    }
+    return RT_OK;
+}
+
+int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int nl)
+{
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    free_scene(d);
+    DevScene &sc = d.scene;
+    sc.ns_padded = (int)ps.sph.size();
+    sc.ns = ps.class_prefix[3 * (size_t)n];
+    sc.np = (int)ps.pl.size();
+    sc.nt = (int)ps.tri_orig.size();
+    sc.nl = nl;
+    sc.nprims = n;
+    int rc;
+    if ((rc = upload(ctx, d, ps.sph, &sc.sph)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.sph_orig, &sc.sph_orig)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.pl, &sc.pl)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.pl_orig, &sc.pl_orig)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.tri, &sc.tri)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.tri_orig, &sc.tri_orig)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.geo, &sc.geo)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.mat, &sc.mat)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.light_pos, &sc.light_pos)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.light_col, &sc.light_col)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.class_prefix, &sc.class_prefix)) != RT_OK) return rc;
+    HIP_TRY(ctx, hipMalloc((void **)&d.sph_cam, std::max<size_t>(ps.sph.size() * sizeof(float4), 16)));
+    sc.sph_cam = d.sph_cam;
+    return RT_OK;
+}
+
+// GetRayDirection's per-frame part, MyApplication.cs:431-448.
+DevCamera make_camera(const rt_camera *cam, int w, int h, int row_begin, int row_end)
+{
+    DevCamera c{};
+    const float deg2rad = 3.14159274f / 180.0f;  // MathHelper.DegreesToRadians: MathF.PI / 180f
+    const float aspect = (float)w / (float)h;
+    const float angle_h = (cam->fov_deg * aspect) * deg2rad;
+    const float angle_v = cam->fov_deg * deg2rad;
+    c.tan_h = (float)std::tan((double)(angle_h / 2.0f));
+    c.tan_v = (float)std::tan((double)(angle_v / 2.0f));
+    const float *u = cam->up, *d = cam->direction;
+    // Vector3.Cross(up, direction).Normalized()
+    float lx = (u[1] * d[2]) - (u[2] * d[1]);
+    float ly = (u[2] * d[0]) - (u[0] * d[2]);
+    float lz = (u[0] * d[1]) - (u[1] * d[0]);
+    const float scale = 1.0f / std::sqrt(((lx * lx) + (ly * ly)) + (lz * lz));
+    c.left[0] = lx * scale;
+    c.left[1] = ly * scale;
+    c.left[2] = lz * scale;
+    for (int k = 0; k < 3; k++) {
+        c.pos[k] = cam->position[k];
+        c.dir[k] = d[k];
+        c.up[k] = u[k];
+    }
+    c.width = w;
+    c.height = h;
+    c.row_begin = row_begin;
+    c.row_end = row_end;
+    return c;
+}
+
+int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
+{
+    const int levels = max_depth + 1;
+    const size_t slots = (size_t)P * (size_t)levels;
+    if (slots > (size_t)INT32_MAX)
+        return fail(ctx, RT_ERR_LIMIT, "%d pixels x %d levels exceeds 2^31-1 hit-record slots", P, levels);
+    const int words = std::max(1, (nl + 31) / 32);
+    if (slots > d.cap_slots) {
+        if (d.frame.recA) (void)hipFree(d.frame.recA);
+        if (d.frame.recB) (void)hipFree(d.frame.recB);
+        if (d.frame.refl) (void)hipFree(d.frame.refl);
+        d.frame.recA = d.frame.recB = d.frame.refl = nullptr;
+        d.cap_slots = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&d.frame.recA, slots * sizeof(float4)));
+        HIP_TRY(ctx, hipMalloc((void **)&d.frame.recB, slots * sizeof(float4)));
+        HIP_TRY(ctx, hipMalloc((void **)&d.frame.refl, slots * sizeof(float4)));
+        d.cap_slots = slots;
+    }
+    if (slots * words > d.cap_mask) {
+        if (d.frame.mask) (void)hipFree(d.frame.mask);
+        d.frame.mask = nullptr;
+        d.cap_mask = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&d.frame.mask, slots * words * sizeof(uint32_t)));
+        d.cap_mask = slots * words;
+    }
+    if (levels + 1 > d.cap_levels) {
+        if (d.frame.cnt) (void)hipFree(d.frame.cnt);
+        d.frame.cnt = nullptr;
+        d.cap_levels = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&d.frame.cnt, 2 * (size_t)(levels + 1) * sizeof(int)));
+        d.cap_levels = levels + 1;
+    }
+    if (!d.frame.counters) HIP_TRY(ctx, hipMalloc((void **)&d.frame.counters, sizeof(DevCounters)));
+    d.frame.P = P;
+    d.frame.slots = (int)slots;
+    d.frame.max_depth = max_depth;
+    d.frame.mask_words = words;
+    return RT_OK;
+}
+
+int check_render_args(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!cam) return fail(ctx, RT_ERR_INVALID_ARG, "camera is NULL");
+    if (w <= 0 || h <= 0) return fail(ctx, RT_ERR_INVALID_ARG, "bad frame size %d x %d", w, h);
+    if (max_depth < 0 || max_depth > RT_MAX_DEPTH)
+        return fail(ctx, RT_ERR_INVALID_ARG, "max_depth %d outside [0, %d]", max_depth, RT_MAX_DEPTH);
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_render before rt_set_scene");
+    const uint32_t missing = ctx->textures_used & ~ctx->textures_loaded;
+    if (missing) {
+        int slot = 0;
+        while (!((missing >> slot) & 1u)) slot++;
+        return fail(ctx, RT_ERR_BAD_TEXTURE, "a primitive uses texture slot %d, which is not loaded", slot);
+    }
+    return RT_OK;
+}
+
+// Enqueue the whole frame pipeline for rows [y0, y1) on device state d.
+int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h, int y0, int y1,
+                 int max_depth, int32_t *dev_pixels, hipStream_t stream)
+{
+    const long long P64 = (long long)(y1 - y0) * (long long)w;
+    if (P64 > INT32_MAX) return fail(ctx, RT_ERR_LIMIT, "row block of %lld pixels exceeds 2^31-1", P64);
+    const int P = (int)P64;
+    d.last_P = P;
+    d.last_depth = max_depth;
+    if (P == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    int rc = ensure_frame(ctx, d, P, max_depth, d.scene.nl);
+    if (rc != RT_OK) return rc;
+    const DevCamera dc = make_camera(cam, w, h, y0, y1);
+    const DevFrame &f = d.frame;
+    HIP_TRY(ctx, hipMemsetAsync(f.cnt, 0, 2 * (size_t)(max_depth + 2) * sizeof(int), stream));
+    HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, sizeof(DevCounters), stream));
+    d.timed = ctx->profiling && stream == d.stream;
+    if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
+    rtk_setup_camera(d.scene, dc, d.sph_cam, stream);
+    rtk_primary(d.scene, dc, f, dev_pixels, stream);
+    if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[1], stream));
+    const int blocks = std::max(1, std::min((P + 255) / 256, d.num_cus * 8));
+    for (int k = 0; k <= max_depth; k++) rtk_trace_level(d.scene, f, k, blocks, stream);
+    if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[2], stream));
+    for (int k = max_depth; k >= 0; k--) rtk_shade_level(d.scene, f, k, dev_pixels, blocks, stream);
+    if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[3], stream));
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_api_version(void) { return RT_API_VERSION; }
+
+int rt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return RT_ERR_NO_DEVICE;
+    return n;
+}
+
+int rt_create(rt_ctx **out, const int *device_ids, int n_devices)
+{
+    if (!out) return fail(nullptr, RT_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device is visible");
+    std::vector<int> ids;
+    if (!device_ids || n_devices <= 0) ids.push_back(0);
+    else ids.assign(device_ids, device_ids + n_devices);
+    for (int id : ids)
+        if (id < 0 || id >= count)
+            return fail(nullptr, RT_ERR_NO_DEVICE, "device id %d outside [0, %d)", id, count);
+    rt_ctx *ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return fail(nullptr, RT_ERR_OUT_OF_MEMORY, "out of host memory");
+    ctx->dev.resize(ids.size());
+    for (size_t i = 0; i < ids.size(); i++) {
+        DeviceState &d = ctx->dev[i];
+        d.device = ids[i];
+        hipDeviceProp_t prop;
+        hipError_t e = hipSetDevice(d.device);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, d.device);
+        if (e == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            int rc = fail(nullptr, RT_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                          d.device, prop.gcnArchName);
+            rt_destroy(ctx);
+            return rc;
+        }
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
+        for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipEventCreate(&d.ev[k]);
+        if (e != hipSuccess) {
+            int rc = fail(nullptr, RT_ERR_HIP, "device %d setup failed: %s", d.device, hipGetErrorString(e));
+            rt_destroy(ctx);
+            return rc;
+        }
+        d.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    // Peer access towards the gathering device (the first one); the copies fall back to
+    // staging through the host when it is not available.
+    for (size_t i = 1; i < ctx->dev.size(); i++) {
+        if (ctx->dev[i].device == ctx->dev[0].device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, ctx->dev[i].device, ctx->dev[0].device) == hipSuccess && can) {
+            (void)hipSetDevice(ctx->dev[i].device);
+            hipError_t e = hipDeviceEnablePeerAccess(ctx->dev[0].device, 0);
+            if (e != hipSuccess) (void)hipGetLastError();  // already enabled is fine
+        }
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx *ctx)
+{
+    if (!ctx) return;
+    for (DeviceState &d : ctx->dev) {
+        (void)hipSetDevice(d.device);
+        if (d.stream) (void)hipStreamSynchronize(d.stream);
+        free_scene(d);
+        for (int t = 0; t < RT_MAX_TEXTURES; t++)
+            if (d.tex_mem[t]) (void)hipFree(d.tex_mem[t]);
+        free_frame(d);
+        for (int k = 0; k < 5; k++)
+            if (d.ev[k]) (void)hipEventDestroy(d.ev[k]);
+        if (d.stream) (void)hipStreamDestroy(d.stream);
+    }
+    if (ctx->staging) (void)hipHostFree(ctx->staging);
+    delete ctx;
+}
+
+const char *rt_last_error(const rt_ctx *ctx)
+{
+    return ctx ? ctx->error.c_str() : g_create_error.c_str();
+}
+
+int rt_set_profiling(rt_ctx *ctx, int enable)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    ctx->profiling = enable != 0;
+    return RT_OK;
+}
+
+int rt_set_scene(rt_ctx *ctx, const rt_scene *s)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!s) return fail(ctx, RT_ERR_INVALID_ARG, "scene is NULL");
+    if (s->num_prims < 0 || s->num_lights < 0)
+        return fail(ctx, RT_ERR_INVALID_ARG, "negative primitive or light count");
+    if (s->num_prims > 0 &&
+        (!s->prim_types || !s->prim_positions || !s->prim_normals || !s->prim_diffuse || !s->prim_glossy ||
+         !s->prim_ambient || !s->prim_specular || !s->prim_radius || !s->prim_d || !s->prim_v0 ||
+         !s->prim_v1 || !s->prim_v2 || !s->prim_checkerboard))
+        return fail(ctx, RT_ERR_INVALID_ARG, "a primitive array is NULL");
+    if (s->num_lights > 0 && (!s->light_positions || !s->light_colors))
+        return fail(ctx, RT_ERR_INVALID_ARG, "a light array is NULL");
+    PackedScene ps;
+    int rc;
+    try {
+        rc = pack_scene(ctx, s, ps);
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, RT_ERR_OUT_OF_MEMORY, "out of host memory while packing the scene");
+    }
+    if (rc != RT_OK) return rc;
+    ctx->have_scene = false;
+    for (DeviceState &d : ctx->dev)
+        if ((rc = upload_scene(ctx, d, ps, s->num_prims, s->num_lights)) != RT_OK) return rc;
+    ctx->num_prims = s->num_prims;
+    ctx->num_lights = s->num_lights;
+    ctx->ns = ps.class_prefix[3 * (size_t)s->num_prims];
+    ctx->np = (int)ps.pl.size();
+    ctx->nt = (int)ps.tri_orig.size();
+    ctx->textures_used = ps.textures_used;
+    ctx->have_scene = true;
+    return RT_OK;
+}
+
+int rt_set_texture(rt_ctx *ctx, int slot, const uint8_t *rgba8, int width, int height)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= RT_MAX_TEXTURES)
+        return fail(ctx, RT_ERR_INVALID_ARG, "texture slot %d outside [0, %d)", slot, RT_MAX_TEXTURES);
+    if (!rgba8 || width <= 0 || height <= 0)
+        return fail(ctx, RT_ERR_INVALID_ARG, "bad texture image (%p, %d x %d)", (const void *)rgba8, width, height);
+    const size_t bytes = (size_t)width * (size_t)height * 4;
+    for (DeviceState &d : ctx->dev) {
+        HIP_TRY(ctx, hipSetDevice(d.device));
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+        if (d.tex_mem[slot]) (void)hipFree(d.tex_mem[slot]);
+        d.tex_mem[slot] = nullptr;
+        d.scene.tex[slot] = nullptr;
+        ctx->textures_loaded &= ~(1u << slot);
+        HIP_TRY(ctx, hipMalloc(&d.tex_mem[slot], bytes));
+        HIP_TRY(ctx, hipMemcpy(d.tex_mem[slot], rgba8, bytes, hipMemcpyHostToDevice));
+        d.scene.tex[slot] = static_cast<const uchar4 *>(d.tex_mem[slot]);
+        d.scene.tex_w[slot] = width;
+        d.scene.tex_h[slot] = height;
+    }
+    ctx->textures_loaded |= 1u << slot;
+    return RT_OK;
+}
+
+int rt_render_rows_device(rt_ctx *ctx, const rt_camera *cam, int w, int h, int row_begin, int row_end,
+                          int max_depth, int32_t *dev_pixels_out, void *hip_stream)
+{
+    int rc = check_render_args(ctx, cam, w, h, max_depth);
+    if (rc != RT_OK) return rc;
+    if (row_begin < 0 || row_end > h || row_begin > row_end)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rows [%d, %d) outside [0, %d)", row_begin, row_end, h);
+    if (!dev_pixels_out && row_end > row_begin) return fail(ctx, RT_ERR_INVALID_ARG, "dev_pixels_out is NULL");
+    DeviceState &d = ctx->dev[0];
+    ctx->last_was_rows_device = true;
+    ctx->last_w = w;
+    ctx->last_h = h;
+    ctx->copy_ms = ctx->gather_ms = 0.0;
+    for (size_t i = 1; i < ctx->dev.size(); i++) ctx->dev[i].last_P = 0;
+    return enqueue_rows(ctx, d, cam, w, h, row_begin, row_end, max_depth, dev_pixels_out,
+                        hip_stream ? static_cast<hipStream_t>(hip_stream) : d.stream);
+}
+
+int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, int32_t *pixels_out)
+{
+    int rc = check_render_args(ctx, cam, w, h, max_depth);
+    if (rc != RT_OK) return rc;
+    if (!pixels_out) return fail(ctx, RT_ERR_INVALID_ARG, "pixels_out is NULL");
+    const long long total = (long long)w * (long long)h;
+    if (total > INT32_MAX) return fail(ctx, RT_ERR_LIMIT, "frame of %lld pixels exceeds 2^31-1", total);
+    const int G = (int)ctx->dev.size();
+    ctx->last_was_rows_device = false;
+    ctx->last_w = w;
+    ctx->last_h = h;
+
+    // Contiguous row blocks, one per device (rows like the outer Parallel.For).
+    ctx->last_rows.assign(G + 1, 0);
+    for (int g = 0; g <= G; g++) ctx->last_rows[g] = (int)(((long long)h * g) / G);
+
+    DeviceState &root = ctx->dev[0];
+    HIP_TRY(ctx, hipSetDevice(root.device));
+    if ((size_t)total > root.cap_out) {
+        if (root.out) (void)hipFree(root.out);
+        root.out = nullptr;
+        root.cap_out = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&root.out, (size_t)total * sizeof(int32_t)));
+        root.cap_out = (size_t)total;
+    }
+    if ((size_t)total > ctx->cap_staging) {
+        if (ctx->staging) (void)hipHostFree(ctx->staging);
+        ctx->staging = nullptr;
+        ctx->cap_staging = 0;
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->staging, (size_t)total * sizeof(int32_t), hipHostMallocDefault));
+        ctx->cap_staging = (size_t)total;
+    }
+    // Device g renders its block; device 0 writes straight into the full frame.
+    for (int g = 0; g < G; g++) {
+        DeviceState &d = ctx->dev[g];
+        const int y0 = ctx->last_rows[g], y1 = ctx->last_rows[g + 1];
+        const size_t block = (size_t)(y1 - y0) * (size_t)w;
+        int32_t *target = root.out + (size_t)y0 * (size_t)w;
+        if (g > 0) {
+            HIP_TRY(ctx, hipSetDevice(d.device));
+            if (block > d.cap_out) {
+                if (d.out) (void)hipFree(d.out);
+                d.out = nullptr;
+                d.cap_out = 0;
+                HIP_TRY(ctx, hipMalloc((void **)&d.out, std::max<size_t>(block, 1) * sizeof(int32_t)));
+                d.cap_out = block;
+            }
+            target = d.out;
+        }
+        if ((rc = enqueue_rows(ctx, d, cam, w, h, y0, y1, max_depth, target, d.stream)) != RT_OK) return rc;
+    }
+    // Gather: every other device writes its block into device 0's frame (one copy per
+    // device, each over its own link), then one copy to the host.
+    for (int g = 1; g < G; g++) {
+        DeviceState &d = ctx->dev[g];
+        const int y0 = ctx->last_rows[g], y1 = ctx->last_rows[g + 1];
+        const size_t bytes = (size_t)(y1 - y0) * (size_t)w * sizeof(int32_t);
+        if (bytes == 0) continue;
+        HIP_TRY(ctx, hipSetDevice(d.device));
+        HIP_TRY(ctx, hipMemcpyPeerAsync(root.out + (size_t)y0 * (size_t)w, root.device, d.out, d.device, bytes,
+                                        d.stream));
+        if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[4], d.stream));
+    }
+    ctx->gather_ms = 0.0;
+    for (int g = G - 1; g >= 0; g--) {
+        DeviceState &d = ctx->dev[g];
+        HIP_TRY(ctx, hipSetDevice(d.device));
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+        if (g > 0 && d.timed && d.last_P > 0) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, d.ev[3], d.ev[4]) == hipSuccess)
+                ctx->gather_ms = std::max(ctx->gather_ms, (double)ms);
+        }
+    }
+    // D2H into pinned staging, then into the caller's (pageable) array.
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->staging, root.out, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                root.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(root.stream));
+    memcpy(pixels_out, ctx->staging, (size_t)total * sizeof(int32_t));
+    ctx->copy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
+int rt_get_stats(rt_ctx *ctx, rt_stats *out)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!out) return fail(ctx, RT_ERR_INVALID_ARG, "out is NULL");
+    memset(out, 0, sizeof *out);
+    out->num_devices = (int32_t)ctx->dev.size();
+    double kernel_ms = 0.0, primary_ms = 0.0, trace_ms = 0.0, shade_ms = 0.0;
+    for (DeviceState &d : ctx->dev) {
+        if (d.last_P == 0 || !d.frame.cnt) continue;
+        HIP_TRY(ctx, hipSetDevice(d.device));
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        std::vector<int> cnt(2 * (size_t)(d.last_depth + 2));
+        DevCounters c{};
+        HIP_TRY(ctx, hipMemcpy(cnt.data(), d.frame.cnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(&c, d.frame.counters, sizeof c, hipMemcpyDeviceToHost));
+        uint64_t hits = 0, secondary = 0;
+        for (int k = 0; k <= d.last_depth; k++) {
+            hits += (uint64_t)cnt[2 * k] + (uint64_t)cnt[2 * k + 1];
+            secondary += (uint64_t)cnt[2 * k];
+        }
+        const uint64_t P = (uint64_t)d.last_P;
+        out->rays_primary += P;
+        out->shaded_hits += hits;
+        out->rays_shadow += hits * (uint64_t)d.scene.nl;
+        out->rays_secondary += secondary;
+        out->sphere_tests += c.sphere_tests + P * (uint64_t)d.scene.ns;
+        out->plane_tests += c.plane_tests + P * (uint64_t)d.scene.np;
+        out->triangle_tests += c.triangle_tests + P * (uint64_t)d.scene.nt;
+        if (d.timed) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, d.ev[0], d.ev[3]) == hipSuccess) kernel_ms = std::max(kernel_ms, (double)ms);
+            if (hipEventElapsedTime(&ms, d.ev[0], d.ev[1]) == hipSuccess) primary_ms = std::max(primary_ms, (double)ms);
+            if (hipEventElapsedTime(&ms, d.ev[1], d.ev[2]) == hipSuccess) trace_ms = std::max(trace_ms, (double)ms);
+            if (hipEventElapsedTime(&ms, d.ev[2], d.ev[3]) == hipSuccess) shade_ms = std::max(shade_ms, (double)ms);
+        }
+    }
+    out->kernel_ms = kernel_ms;
+    out->primary_ms = primary_ms;
+    out->trace_ms = trace_ms;
+    out->shade_ms = shade_ms;
+    out->gather_ms = ctx->gather_ms;
+    out->copy_ms = ctx->copy_ms;
+    return RT_OK;
+}
+
+}  // extern "C"

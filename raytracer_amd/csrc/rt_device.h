@@ -1,0 +1,107 @@
+// rt_device.h — data layout shared by the host side (rt_api.cpp) and the kernels
+// (rt_kernels.hip) of librt_hip.so.  gfx950 only.
+//
+// Scene in HBM (structure of arrays, one array per primitive class, each in the
+// host's insertion order; *_orig maps back to the host's primitive index, which is
+// what decides ties in closest-hit, MyApplication.cs:361):
+//   sph      float4 {cx, cy, cz, r*r}        one per sphere
+//   sph_cam  float4 {ox-cx, oy-cy, oz-cz, c} per frame, c = |o-p|^2 - r*r for the
+//                                            camera origin o (objects.cs:113-114)
+//   pl       float4 {nx, ny, nz, d}          one per plane
+//   tri      float4 x3 {v0}, {e1}, {e2}      e1 = v1-v0, e2 = v2-v0 (objects.cs:238-239)
+//   geo      float4 per host primitive: sphere centre or plane/triangle normal
+//   mat      float4 x3 per host primitive: {diffuse.rgb, specular},
+//            {glossy.rgb, flags}, {ambient.rgb, -}
+//   light_pos / light_col  float4 per light
+// All of it is wave-uniform in every kernel, so it is read through the scalar cache.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_DEV_MAX_TEXTURES 8
+
+// mat[3*i+1].w holds these flags (bit pattern of an int stored in a float slot).
+#define RT_MF_TYPE_MASK   0x3      // RT_PRIM_*
+#define RT_MF_CHECKER     0x4      // plane with Material.useCheckerboard
+#define RT_MF_TEX_SHIFT   4        // texture slot + 1 in bits 4..7 (0 = none)
+#define RT_MF_TEX_MASK    0xF0
+
+// sph, sph_cam and sph_orig are padded to a multiple of RT_SPH_PAD entries; the padding
+// is {0, 0, 0, -inf}, which makes c = +inf so that no ray passes the sphere filter.
+#define RT_SPH_PAD 4
+
+struct DevScene {
+    int ns, np, nt, nl, nprims;
+    int ns_padded;
+    const float4 *sph;
+    const float4 *sph_cam;
+    const int *sph_orig;
+    const float4 *pl;
+    const int *pl_orig;
+    const float4 *tri;
+    const int *tri_orig;
+    const float4 *geo;
+    const float4 *mat;
+    const float4 *light_pos;
+    const float4 *light_col;
+    // class_prefix[3*i + c] = number of primitives of class c among host primitives
+    // [0, i): lets a kernel turn "first occluder index" into per-class test counts.
+    const int *class_prefix;
+    const uchar4 *tex[RT_DEV_MAX_TEXTURES];
+    int tex_w[RT_DEV_MAX_TEXTURES];
+    int tex_h[RT_DEV_MAX_TEXTURES];
+};
+
+// Per-frame camera constants, computed on the host with the float/double sequence of
+// GetRayDirection (MyApplication.cs:431-448); only sx, sy vary per pixel.
+struct DevCamera {
+    float pos[3];
+    float dir[3];
+    float up[3];
+    float left[3];   // Normalized(Cross(up, dir))
+    float tan_h;     // (float)Math.Tan(angleH / 2)
+    float tan_v;     // (float)Math.Tan(angleV / 2)
+    int width, height;
+    int row_begin, row_end;
+};
+
+// Device-side counters of one render call.
+struct DevCounters {
+    unsigned long long sphere_tests;
+    unsigned long long plane_tests;
+    unsigned long long triangle_tests;
+    unsigned long long pad;
+};
+
+// Hit records: the bounce stack of every pixel, kept in HBM.  Level k of the frame
+// owns slots [k*P, (k+1)*P) (P = pixels of the render call).  Records whose surface
+// needs a reflection trace ("A": specular != 0 and k < max_depth) are appended from
+// the front of the level, the others ("B") from the back, so each level is two dense
+// queues and no index arrays are needed.
+//   recA[slot] = {hit.xyz, prim}          prim = host primitive index (int bits)
+//   recB[slot] = {view.xyz, parent}       parent = slot of the level k-1 record, or
+//                                         the pixel index at level 0 (int bits)
+//   refl[slot] = {rgb of the reflected Shade(), valid}   written by the child
+//   mask[w*slots + slot] = bit l%32 of word l/32 set when light l is occluded
+struct DevFrame {
+    float4 *recA;
+    float4 *recB;
+    float4 *refl;
+    uint32_t *mask;
+    int *cnt;              // cnt[2*k] = A records of level k, cnt[2*k+1] = B records
+    DevCounters *counters;
+    int P;                 // pixels of this render call
+    int slots;             // P * (max_depth + 1)
+    int max_depth;
+    int mask_words;        // ceil(nl / 32), at least 1
+};
+
+// Launch wrappers (rt_kernels.hip).  All enqueue on `stream` and return at once.
+void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, hipStream_t stream);
+void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels,
+                 hipStream_t stream);
+void rtk_trace_level(const DevScene &s, const DevFrame &f, int level, int grid_blocks,
+                     hipStream_t stream);
+void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
+                     int grid_blocks, hipStream_t stream);

@@ -1,0 +1,665 @@
+// rt_kernels.hip — gfx950 kernels of the render loop.
+//
+// Arithmetic contract: every FP32 expression is evaluated operation by operation in
+// the order the reference's C# evaluates it (no FMA contraction: this file is built
+// with -ffp-contract=off; IEEE divide and square root), and double precision is used
+// exactly where the reference calls System.Math (sin, pow).  Rearrangements below are
+// limited to ones that are exact in IEEE arithmetic and each says why.
+//
+// Pipeline per frame (one HIP stream, in order):
+//   setup_camera   per sphere: o-p and c for the camera origin (shared by all pixels)
+//   primary        per pixel: ray direction, closest hit -> level-0 hit record
+//   trace_level k  per hit record: its light rays (any-hit) and, if the surface is
+//                  specular and k < max_depth, its reflection ray (closest hit) walk the
+//                  scene ONCE together, sharing the origin-dependent terms
+//   shade_level k  (k = max_depth .. 0) Primitive.Shade for every record of the level;
+//                  the colour goes to the parent record or, at level 0, to the pixel
+// The per-pixel bounce stack lives in HBM as compacted per-level queues (rt_device.h),
+// so every wave of every level is dense whatever the neighbouring pixels do.
+#include "rt_device.h"
+
+#include <limits.h>
+
+#define RT_EPS 0.0001f
+#define RT_FLT_MAX 3.40282347e+38f
+#define SPH_BATCH RT_SPH_PAD
+
+// ---------------------------------------------------------------------------------------
+// OpenTK.Mathematics Vector3 operators, restated (Dot / Cross / Length / Normalized).
+// ---------------------------------------------------------------------------------------
+struct f3 {
+    float x, y, z;
+};
+// IEEE-754 correctly rounded FP32 divide and square root.  Plain `/` and sqrtf() are
+// that under -fhip-fp32-correctly-rounded-divide-sqrt (set explicitly by the build);
+// the __fdiv_rn / __fsqrt_rn intrinsics are NOT (they map to the 1-ulp native forms).
+__device__ __forceinline__ float ieee_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float ieee_sqrt(float a) { return sqrtf(a); }
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return ((a.x * b.x) + (a.y * b.y)) + (a.z * b.z); }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b)
+{
+    return mk3((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x));
+}
+__device__ __forceinline__ float length3(f3 a) { return ieee_sqrt(dot3(a, a)); }
+__device__ __forceinline__ f3 normalized3(f3 a)
+{
+    float scale = ieee_div(1.0f, length3(a));
+    return mk3(a.x * scale, a.y * scale, a.z * scale);
+}
+__device__ __forceinline__ f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+
+// System.Math.Max(float, float): IEEE 754-2019 maximum (NaN propagates, +0 > -0).
+__device__ __forceinline__ float net_maxf(float a, float b)
+{
+    if (a != b) {
+        if (!(a != a)) return b < a ? a : b;
+        return a;
+    }
+    return (__float_as_int(b) < 0) ? a : b;
+}
+
+// C# (int)float on x64 (cvttss2si): truncate; NaN / out of range -> INT_MIN.
+__device__ __forceinline__ int net_f2i(float f)
+{
+    if (!(f >= -2147483648.0f && f < 2147483648.0f)) return INT_MIN;
+    return (int)f;
+}
+
+// Sphere.Intersect objects.cs:113-121 from x = Dot(d, o-p), c and a = Dot(d, d).
+// Returns false when the discriminant is negative; otherwise t (which may be <= 0).
+__device__ __forceinline__ bool sphere_root(float x, float c, float a, float &t)
+{
+    float b = 2.0f * x;
+    float disc = (b * b) - ((4.0f * a) * c);
+    if (disc < 0.0f) return false;
+    t = ieee_div((-b) - ieee_sqrt(disc), 2.0f * a);
+    return true;
+}
+
+// Cheap exact filter in front of sphere_root.  With m = x*|x| (= -x^2 for x < 0):
+//   -m >= a*c  <=>  x < 0 and x*x >= a*c   (or x >= 0 with c <= 0: origin inside)
+// x*x < a*c is exactly `discriminant < 0` (b*b = 4*fl(x*x) and 4*a*c = 4*fl(a*c) are
+// exact scalings), and x >= 0 gives -b - sqrt(disc) <= 0, i.e. t <= 0, which both
+// Scene.Intersect and IsInShadow discard (t > epsilon).  So every sphere this filter
+// drops is one the reference drops too; the ones it keeps go through sphere_root.
+__device__ __forceinline__ bool sphere_maybe(float x, float ac)
+{
+    float m = x * fabsf(x);
+    return (-m) >= ac;
+}
+
+// Plane.Intersect objects.cs:157-164 from numer = -Dot(n, o) - d.
+__device__ __forceinline__ bool plane_t(f3 n, float numer, f3 d, float &t)
+{
+    float denom = dot3(n, d);
+    if (fabsf(denom) <= 0.0001f) return false;
+    t = ieee_div(numer, denom);
+    return !(t <= 0.0001f);
+}
+
+// Triangle.Intersect objects.cs:240-261 (e1, e2 and s = o - v0 prepared by the caller).
+__device__ __forceinline__ bool triangle_t(f3 e1, f3 e2, f3 sv, f3 d, float &t)
+{
+    f3 h = cross3(d, e2);
+    float a = dot3(e1, h);
+    if (a > -0.0001f && a < 0.0001f) return false;
+    float f = ieee_div(1.0f, a);
+    float u = f * dot3(sv, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 q = cross3(sv, e1);
+    float v = f * dot3(d, q);
+    if (v < 0.0f || (u + v) > 1.0f) return false;
+    t = f * dot3(e2, q);
+    return t > 0.0001f;
+}
+
+// Closest-hit bookkeeping across primitive classes: the reference scans in host order
+// with a strict `<` (MyApplication.cs:361), i.e. it keeps the lexicographic minimum of
+// (t, host index).  Classes are scanned one after the other here, so ties compare the
+// host index explicitly.
+struct Closest {
+    float t;
+    int prim;
+};
+__device__ __forceinline__ void closest_offer(Closest &c, float t, int prim)
+{
+    if (t > RT_EPS && (t < c.t || (t == c.t && prim < c.prim))) {
+        c.t = t;
+        c.prim = prim;
+    }
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Append `flag` lanes to a counter with one atomic per wave; returns the lane's slot
+// offset (valid where flag).  All lanes of the wave must call it.
+__device__ __forceinline__ int wave_append(int *counter, bool flag)
+{
+    unsigned long long m = __ballot(flag);
+    int lane = threadIdx.x & 63;
+    int base = 0;
+    if (m != 0ull) {
+        int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) base = atomicAdd(counter, __popcll(m));
+        base = __shfl(base, leader, 64);
+    }
+    return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ bool material_specular_nonzero(const DevScene &s, int prim)
+{
+    return s.mat[3 * prim].w != 0.0f;
+}
+
+// Write a new hit record of level `level` and return nothing; all lanes call it.
+__device__ __forceinline__ void push_record(const DevFrame &f, const DevScene &s, int level,
+                                            bool valid, int prim, f3 hit, f3 view, int parent)
+{
+    // The reference traces the reflection inside its light loop (objects.cs:49,80-83):
+    // no lights, no trace.
+    bool needs_trace = valid && level < f.max_depth && s.nl > 0 && material_specular_nonzero(s, prim);
+    bool plain = valid && !needs_trace;
+    int ia = wave_append(&f.cnt[2 * level], needs_trace);
+    int ib = wave_append(&f.cnt[2 * level + 1], plain);
+    if (valid) {
+        int slot = needs_trace ? (level * f.P + ia) : ((level + 1) * f.P - 1 - ib);
+        f.recA[slot] = make_float4(hit.x, hit.y, hit.z, __int_as_float(prim));
+        f.recB[slot] = make_float4(view.x, view.y, view.z, __int_as_float(parent));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// setup_camera: per sphere, the terms of Sphere.Intersect that depend only on the ray
+// origin (objects.cs:113-114).  Every primary ray starts at camera.position, so they
+// are computed once per frame instead of once per pixel; same operations, same bits.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam, float4 *sph_cam)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.ns_padded) return;  // padding: c = |o|^2 - (-inf) = +inf
+    float4 sp = s.sph[i];
+    f3 op = sub3(mk3(cam.pos[0], cam.pos[1], cam.pos[2]), xyz(sp));
+    float c = dot3(op, op) - sp.w;
+    sph_cam[i] = make_float4(op.x, op.y, op.z, c);
+}
+
+// ---------------------------------------------------------------------------------------
+// primary: Raytracer.Render's loop body up to scene.Intersect (MyApplication.cs:412-415)
+// plus GetRayDirection (:428-452).  One lane per pixel, 8x8 pixels per wave.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevFrame f, int32_t *pixels)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = cam.row_begin + blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = x < cam.width && y < cam.row_end;
+    // Lanes outside the frame trace the frame's last pixel and write nothing.
+    const int px = inside ? x : cam.width - 1, py = inside ? y : cam.row_end - 1;
+
+    float sx = (ieee_div((float)px, (float)cam.width) * 2.0f) - 1.0f;
+    float sy = (ieee_div((float)py, (float)cam.height) * 2.0f) - 1.0f;
+    sx *= cam.tan_h;
+    sy *= cam.tan_v;
+    const f3 cdir = mk3(cam.dir[0], cam.dir[1], cam.dir[2]);
+    const f3 cup = mk3(cam.up[0], cam.up[1], cam.up[2]);
+    const f3 cleft = mk3(cam.left[0], cam.left[1], cam.left[2]);
+    const f3 o = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
+    const f3 d = normalized3(add3(add3(cdir, scale3(cup, sy)), scale3(cleft, sx)));
+    const float a = dot3(d, d);
+
+    // Spheres, SPH_BATCH at a time: the filter for the whole batch is straight-line code
+    // (one scalar load burst, no branch), and one branch per batch leads to the exact
+    // root computation for the few (lane, sphere) pairs that pass.  Strict `<` within the
+    // class keeps the first of equal distances.  The arrays are padded to a multiple of
+    // SPH_BATCH with entries no ray can pass (c = +inf).
+    float best_t = RT_FLT_MAX;
+    int best_i = -1;
+    const int nsp = s.ns_padded;
+    for (int i = 0; i < nsp; i += SPH_BATCH) {
+        float xx[SPH_BATCH], cc[SPH_BATCH];
+        bool pass[SPH_BATCH];
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < SPH_BATCH; u++) {
+            const float4 sc = s.sph_cam[i + u];
+            xx[u] = dot3(d, mk3(sc.x, sc.y, sc.z));
+            cc[u] = sc.w;
+            pass[u] = sphere_maybe(xx[u], a * sc.w);
+            any = any || pass[u];
+        }
+        if (any) {
+#pragma unroll
+            for (int u = 0; u < SPH_BATCH; u++) {
+                float t;
+                if (pass[u] && sphere_root(xx[u], cc[u], a, t) && t < best_t && t > RT_EPS) {
+                    best_t = t;
+                    best_i = i + u;
+                }
+            }
+        }
+    }
+    Closest c;
+    c.t = best_t;
+    c.prim = best_i >= 0 ? s.sph_orig[best_i] : INT_MAX;
+
+    for (int j = 0; j < s.np; j++) {
+        const float4 pl = s.pl[j];
+        const f3 n = xyz(pl);
+        const float numer = (-dot3(n, o)) - pl.w;
+        float t;
+        if (plane_t(n, numer, d, t)) closest_offer(c, t, s.pl_orig[j]);
+    }
+    for (int j = 0; j < s.nt; j++) {
+        const f3 v0 = xyz(s.tri[3 * j]), e1 = xyz(s.tri[3 * j + 1]), e2 = xyz(s.tri[3 * j + 2]);
+        float t;
+        if (triangle_t(e1, e2, sub3(o, v0), d, t)) closest_offer(c, t, s.tri_orig[j]);
+    }
+
+    const bool hit = inside && c.prim != INT_MAX;
+    const int pix = (py - cam.row_begin) * cam.width + px;
+    const f3 hp = add3(o, scale3(d, c.t));
+    push_record(f, s, 0, hit, hit ? c.prim : 0, hp, d, pix);
+    if (inside && !hit) pixels[pix] = 0;  // MyApplication.cs:423
+}
+
+// ---------------------------------------------------------------------------------------
+// trace_level: for each hit record, IsInShadow towards every light (objects.cs:51-60)
+// and, for specular surfaces below the depth bound, scene.Intersect along the mirror
+// direction (objects.cs:82-83).  All of a record's rays start at its hit point, so
+// o-p, |o-p|^2 and c (objects.cs:113-114) are formed once per sphere and reused by
+// every ray of the record: NR rays cost 9 + 8*NR operations per sphere instead of 17*NR.
+// ---------------------------------------------------------------------------------------
+template <int LC, bool SEC>
+struct Rays {
+    f3 sh_d[LC > 0 ? LC : 1];
+    float sh_a[LC > 0 ? LC : 1];
+    float sh_dist[LC > 0 ? LC : 1];
+    int sh_first[LC > 0 ? LC : 1];  // lowest host index among occluders, INT_MAX if none
+    f3 sec_d;
+    float sec_a;
+    Closest sec;
+};
+
+template <int LC, bool SEC>
+__device__ __forceinline__ void traverse(const DevScene &s, const f3 o, Rays<LC, SEC> &r)
+{
+    // ---- spheres: batches of SPH_BATCH, filter in straight-line code, one branch -------
+    float best_t = RT_FLT_MAX;
+    int best_i = -1;
+    const int nsp = s.ns_padded;
+    constexpr int NR = LC + (SEC ? 1 : 0);
+    for (int i = 0; i < nsp; i += SPH_BATCH) {
+        float cc[SPH_BATCH], xr[SPH_BATCH][NR > 0 ? NR : 1];
+        bool pass[SPH_BATCH][NR > 0 ? NR : 1];
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < SPH_BATCH; u++) {
+            const float4 sp = s.sph[i + u];
+            const f3 op = sub3(o, xyz(sp));
+            cc[u] = dot3(op, op) - sp.w;
+            if (SEC) {
+                xr[u][LC] = dot3(r.sec_d, op);
+                pass[u][LC] = sphere_maybe(xr[u][LC], r.sec_a * cc[u]);
+                any = any || pass[u][LC];
+            }
+#pragma unroll
+            for (int l = 0; l < LC; l++) {
+                xr[u][l] = dot3(r.sh_d[l], op);
+                pass[u][l] = sphere_maybe(xr[u][l], r.sh_a[l] * cc[u]);
+                any = any || pass[u][l];
+            }
+        }
+        if (any) {
+#pragma unroll
+            for (int u = 0; u < SPH_BATCH; u++) {
+                float t;
+                if (SEC) {
+                    if (pass[u][LC] && sphere_root(xr[u][LC], cc[u], r.sec_a, t) && t < best_t &&
+                        t > RT_EPS) {
+                        best_t = t;
+                        best_i = i + u;
+                    }
+                }
+#pragma unroll
+                for (int l = 0; l < LC; l++) {
+                    if (pass[u][l] && sphere_root(xr[u][l], cc[u], r.sh_a[l], t) && t > RT_EPS &&
+                        t < r.sh_dist[l])
+                        r.sh_first[l] = min(r.sh_first[l], s.sph_orig[i + u]);
+                }
+            }
+        }
+    }
+    if (SEC) {
+        r.sec.t = best_t;
+        r.sec.prim = best_i >= 0 ? s.sph_orig[best_i] : INT_MAX;
+    }
+    // ---- planes --------------------------------------------------------------------
+    for (int j = 0; j < s.np; j++) {
+        const float4 pl = s.pl[j];
+        const f3 n = xyz(pl);
+        const float numer = (-dot3(n, o)) - pl.w;
+        const int orig = s.pl_orig[j];
+        float t;
+        if (SEC) {
+            if (plane_t(n, numer, r.sec_d, t)) closest_offer(r.sec, t, orig);
+        }
+#pragma unroll
+        for (int l = 0; l < LC; l++) {
+            if (plane_t(n, numer, r.sh_d[l], t) && t > RT_EPS && t < r.sh_dist[l])
+                r.sh_first[l] = min(r.sh_first[l], orig);
+        }
+    }
+    // ---- triangles -----------------------------------------------------------------
+    for (int j = 0; j < s.nt; j++) {
+        const f3 v0 = xyz(s.tri[3 * j]), e1 = xyz(s.tri[3 * j + 1]), e2 = xyz(s.tri[3 * j + 2]);
+        const f3 sv = sub3(o, v0);
+        const int orig = s.tri_orig[j];
+        float t;
+        if (SEC) {
+            if (triangle_t(e1, e2, sv, r.sec_d, t)) closest_offer(r.sec, t, orig);
+        }
+#pragma unroll
+        for (int l = 0; l < LC; l++) {
+            if (triangle_t(e1, e2, sv, r.sh_d[l], t) && t > RT_EPS && t < r.sh_dist[l])
+                r.sh_first[l] = min(r.sh_first[l], orig);
+        }
+    }
+}
+
+// Surface normal of a record: Sphere.GetNormal objects.cs:128-131, else the stored
+// plane / triangle normal (objects.cs:171-174, 270-273).
+__device__ __forceinline__ f3 record_normal(const DevScene &s, int prim, int type, f3 hit)
+{
+    const float4 g = s.geo[prim];
+    if (type == 0) return normalized3(sub3(hit, xyz(g)));
+    return xyz(g);
+}
+
+struct TestCount {
+    int sph, pl, tri;
+};
+
+// One chunk of LC lights (plus the reflection ray when SEC) for one record.
+template <int LC, bool SEC>
+__device__ __forceinline__ void trace_chunk(const DevScene &s, const f3 hit, const f3 view,
+                                            const f3 normal, int l0, uint32_t &mask_word,
+                                            Closest &sec_out, f3 &sec_dir, TestCount &tc)
+{
+    Rays<LC, SEC> r;
+#pragma unroll
+    for (int l = 0; l < LC; l++) {
+        const f3 lp = xyz(s.light_pos[l0 + l]);
+        const f3 to_light = sub3(lp, hit);
+        r.sh_d[l] = normalized3(to_light);          // objects.cs:51
+        r.sh_dist[l] = length3(to_light);           // objects.cs:52
+        r.sh_a[l] = dot3(r.sh_d[l], r.sh_d[l]);
+        r.sh_first[l] = INT_MAX;
+    }
+    if (SEC) {
+        // objects.cs:82: (viewDir - 2 * Dot(viewDir, normal) * normal).Normalized()
+        r.sec_d = normalized3(sub3(view, scale3(normal, 2.0f * dot3(view, normal))));
+        r.sec_a = dot3(r.sec_d, r.sec_d);
+        r.sec.t = RT_FLT_MAX;
+        r.sec.prim = INT_MAX;
+    }
+    traverse<LC, SEC>(s, hit, r);
+#pragma unroll
+    for (int l = 0; l < LC; l++) {
+        const bool occluded = r.sh_first[l] != INT_MAX;
+        if (occluded) mask_word |= 1u << ((l0 + l) & 31);
+        // Tests the reference executes for this light: primitives up to and including
+        // the first occluder (MyApplication.cs:373-378), all of them when unoccluded.
+        const int upto = occluded ? r.sh_first[l] + 1 : s.nprims;
+        tc.sph += s.class_prefix[3 * upto + 0];
+        tc.pl += s.class_prefix[3 * upto + 1];
+        tc.tri += s.class_prefix[3 * upto + 2];
+    }
+    if (SEC) {
+        sec_out = r.sec;
+        sec_dir = r.sec_d;
+        tc.sph += s.ns;
+        tc.pl += s.np;
+        tc.tri += s.nt;
+    }
+}
+
+template <bool SEC>
+__global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level)
+{
+    const int n = SEC ? f.cnt[2 * level] : f.cnt[2 * level + 1];
+    const int lane_global = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stride = gridDim.x * blockDim.x;
+    TestCount tc = {0, 0, 0};
+    for (int base = lane_global - (threadIdx.x & 63); base < n; base += stride) {
+        const int i = base + (threadIdx.x & 63);
+        const bool active = i < n;
+        const int ii = active ? i : n - 1;
+        const int slot = SEC ? (level * f.P + ii) : ((level + 1) * f.P - 1 - ii);
+        const float4 ra = f.recA[slot], rb = f.recB[slot];
+        const f3 hit = xyz(ra), view = xyz(rb);
+        const int prim = __float_as_int(ra.w);
+        const int type = __float_as_int(s.mat[3 * prim + 1].w) & RT_MF_TYPE_MASK;
+        const f3 normal = record_normal(s, prim, type, hit);
+
+        Closest sec = {RT_FLT_MAX, INT_MAX};
+        f3 sec_dir = mk3(0.0f, 0.0f, 0.0f);
+        TestCount ltc = {0, 0, 0};
+        uint32_t word = 0;
+        int l0 = 0;
+        bool first = true;
+        const int nl = s.nl;
+        // Lights in chunks of 4 / 2 / 1; the reflection ray rides with the first chunk.
+        while (l0 < nl || (SEC && first)) {
+            const int rem = nl - l0;
+            if (rem >= 4) {
+                if (SEC && first) trace_chunk<4, true>(s, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                else trace_chunk<4, false>(s, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                l0 += 4;
+            } else if (rem >= 2) {
+                if (SEC && first) trace_chunk<2, true>(s, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                else trace_chunk<2, false>(s, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                l0 += 2;
+            } else if (rem == 1) {
+                if (SEC && first) trace_chunk<1, true>(s, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                else trace_chunk<1, false>(s, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                l0 += 1;
+            } else {
+                trace_chunk<0, true>(s, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            }
+            first = false;
+            if (l0 > 0 && ((l0 & 31) == 0 || l0 >= nl)) {
+                if (active) f.mask[(size_t)((l0 - 1) >> 5) * (size_t)f.slots + slot] = word;
+                word = 0;
+            }
+        }
+        if (active) {
+            tc.sph += ltc.sph;
+            tc.pl += ltc.pl;
+            tc.tri += ltc.tri;
+        }
+        if (SEC) {
+            const bool child = active && sec.prim != INT_MAX;
+            const f3 hit2 = add3(hit, scale3(sec_dir, sec.t));   // objects.cs:123,166,263
+            if (active) f.refl[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            push_record(f, s, level + 1, child, child ? sec.prim : 0, hit2, sec_dir, slot);
+        }
+    }
+    const int ws = wave_sum(tc.sph), wp = wave_sum(tc.pl), wt = wave_sum(tc.tri);
+    if ((threadIdx.x & 63) == 0 && (ws | wp | wt) != 0) {
+        atomicAdd(&f.counters->sphere_tests, (unsigned long long)ws);
+        atomicAdd(&f.counters->plane_tests, (unsigned long long)wp);
+        atomicAdd(&f.counters->triangle_tests, (unsigned long long)wt);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// shade_level: Primitive.Shade objects.cs:44-96 for every record of a level, with the
+// occlusion bits from trace_level and the reflected colour its child left in refl[].
+// The alpha channel is not carried: it never reaches an RGB value or MixColor.
+// ---------------------------------------------------------------------------------------
+
+// (float)Math.Pow(x, 250) for the Phong term (objects.cs:77-78).  x^250 by repeated
+// squaring in double: 250 = 128+64+32+16+8+2.  Relative error <= ~250 * 2^-53, i.e.
+// the value rounds to the same float as a correctly rounded pow except within
+// ~3e-14 (relative) of a float rounding boundary.
+__device__ __forceinline__ float pow250(float xf)
+{
+    const double x = (double)xf;
+    const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16,
+                 x64 = x32 * x32, x128 = x64 * x64;
+    return (float)(((((x128 * x64) * x32) * x16) * x8) * x2);
+}
+
+// Plane.GetCheckerboardColor objects.cs:176-188: 1 = white.
+__device__ __forceinline__ bool checker_white(f3 hit)
+{
+    const float scale = 7.5f;
+    const float sines = (float)((sin((double)(hit.x * scale)) * sin((double)(hit.y * scale))) *
+                                sin((double)(hit.z * scale)));
+    return !(sines < 0.0f);
+}
+
+// Plane.GetTextureCoordinates objects.cs:190-204 + Texture.GetColor :348-353 +
+// LoadTexture :343.  `% 1` is fmodf(x, 1) = x - trunc(x), exact in FP32.  The reference
+// throws for addresses outside the image (NaN / inf coordinates); clamp instead.
+__device__ __forceinline__ f3 texture_color(const DevScene &s, int slot, f3 hit)
+{
+    const float fu = ieee_div(hit.x, 5.0f) - 0.5f, fv = ieee_div(hit.y, 5.0f) - 0.2f;
+    float u = fu - truncf(fu), v = fv - truncf(fv);
+    u = -u;
+    if (u < 0.0f) u += 1.0f;
+    if (v < 0.0f) v += 1.0f;
+    const int w = s.tex_w[slot], h = s.tex_h[slot];
+    int tx = net_f2i(u * (float)(w - 1)), ty = net_f2i(v * (float)(h - 1));
+    tx = min(max(tx, 0), w - 1);
+    ty = min(max(ty, 0), h - 1);
+    const uchar4 p = s.tex[slot][(size_t)ty * (size_t)w + (size_t)tx];
+    return mk3(ieee_div((float)p.x, 255.0f), ieee_div((float)p.y, 255.0f),
+               ieee_div((float)p.z, 255.0f));
+}
+
+__device__ __forceinline__ float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+
+__global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level, int32_t *pixels)
+{
+    const int na = f.cnt[2 * level], nb = f.cnt[2 * level + 1];
+    const int n = na + nb;
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int slot = i < na ? (level * f.P + i) : ((level + 1) * f.P - 1 - (i - na));
+        const float4 ra = f.recA[slot], rb = f.recB[slot];
+        const f3 hit = xyz(ra), view = xyz(rb);
+        const int prim = __float_as_int(ra.w), parent = __float_as_int(rb.w);
+        const float4 m0 = s.mat[3 * prim], m1 = s.mat[3 * prim + 1], m2 = s.mat[3 * prim + 2];
+        const int flags = __float_as_int(m1.w);
+        const int type = flags & RT_MF_TYPE_MASK;
+        const f3 normal = record_normal(s, prim, type, hit);
+        const float specular = m0.w;
+        const f3 mat_glossy = xyz(m1), mat_ambient = xyz(m2);
+
+        // Surface colour under the light: material, texture or checkerboard
+        // (objects.cs:62-74); the same for every light, so looked up once.
+        f3 base = xyz(m0);
+        if (type == 1) {
+            const int tex = (flags & RT_MF_TEX_MASK) >> RT_MF_TEX_SHIFT;
+            if (tex != 0) base = texture_color(s, tex - 1, hit);
+            else if (flags & RT_MF_CHECKER) {
+                const float cw = checker_white(hit) ? 1.0f : 0.0f;
+                base = mk3(cw, cw, cw);
+            }
+        }
+        // Reflected colour (objects.cs:80-88): present when this record traced a
+        // reflection ray that hit something.
+        bool have_refl = false;
+        f3 refl_term = mk3(0.0f, 0.0f, 0.0f);
+        if (i < na) {
+            const float4 rf = f.refl[slot];
+            have_refl = rf.w != 0.0f;
+            // (Vector4)Shade(..) * material.specular * 1
+            refl_term = scale3(scale3(xyz(rf), specular), 1.0f);
+        }
+
+        f3 final = mk3(0.0f, 0.0f, 0.0f);
+        const int nl = s.nl;
+        uint32_t word = 0;
+        for (int l = 0; l < nl; l++) {
+            if ((l & 31) == 0) word = f.mask[(size_t)(l >> 5) * (size_t)f.slots + slot];
+            const f3 lp = xyz(s.light_pos[l]), lc = xyz(s.light_col[l]);
+            const f3 to_light = sub3(lp, hit);
+            const f3 shadow_ray = normalized3(to_light);
+            const float distance = length3(to_light);
+            float diffuse = net_maxf(dot3(normal, shadow_ray), 0.0f);
+            float glossy = 1.0f;
+            if ((word >> (l & 31)) & 1u) {
+                diffuse = 0.0f;
+                glossy = 0.0f;
+            }
+            const f3 diffuse_color = scale3(base, diffuse);
+            const f3 reflection = sub3(shadow_ray, scale3(normal, 2.0f * dot3(shadow_ray, normal)));
+            const float sp = pow250(net_maxf(dot3(reflection, view), 0.0f));
+            const f3 glossy_color = scale3(scale3(mat_glossy, sp), glossy);
+            const float d2 = distance * distance;
+            if (have_refl) {
+                final = add3(final, mk3(ieee_div(refl_term.x, d2), ieee_div(refl_term.y, d2),
+                                        ieee_div(refl_term.z, d2)));
+            }
+            // light.color * 1 / (distance*distance) * (diffuseColor + glossyColor) + ambient
+            const f3 li = mk3(ieee_div(lc.x * 1.0f, d2), ieee_div(lc.y * 1.0f, d2),
+                              ieee_div(lc.z * 1.0f, d2));
+            const f3 dg = add3(diffuse_color, glossy_color);
+            const f3 term = add3(mk3(li.x * dg.x, li.y * dg.y, li.z * dg.z), mat_ambient);
+            final = add3(final, term);
+        }
+        final = mk3(clamp01(final.x), clamp01(final.y), clamp01(final.z));  // objects.cs:94
+
+        if (level == 0) {
+            // Primitive.MixColor objects.cs:35-41 -> Surface.pixels (MyApplication.cs:420)
+            const uint32_t r = (uint32_t)net_f2i(final.x * 255.0f);
+            const uint32_t g = (uint32_t)net_f2i(final.y * 255.0f);
+            const uint32_t b = (uint32_t)net_f2i(final.z * 255.0f);
+            pixels[parent] = (int32_t)((r << 16) + (g << 8) + b);
+        } else {
+            f.refl[parent] = make_float4(final.x, final.y, final.z, 1.0f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------
+void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, hipStream_t stream)
+{
+    if (s.ns_padded <= 0) return;
+    hipLaunchKernelGGL(k_setup_camera, dim3((s.ns_padded + 255) / 256), dim3(256), 0, stream, s, cam, sph_cam);
+}
+
+void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels,
+                 hipStream_t stream)
+{
+    const int rows = cam.row_end - cam.row_begin;
+    dim3 grid((cam.width + 15) / 16, (rows + 15) / 16);
+    hipLaunchKernelGGL(k_primary, grid, dim3(256), 0, stream, s, cam, f, pixels);
+}
+
+void rtk_trace_level(const DevScene &s, const DevFrame &f, int level, int grid_blocks,
+                     hipStream_t stream)
+{
+    if (level < f.max_depth)
+        hipLaunchKernelGGL(k_trace<true>, dim3(grid_blocks), dim3(256), 0, stream, s, f, level);
+    hipLaunchKernelGGL(k_trace<false>, dim3(grid_blocks), dim3(256), 0, stream, s, f, level);
+}
+
+void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
+                     int grid_blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_shade, dim3(grid_blocks), dim3(256), 0, stream, s, f, level, pixels);
+}

@@ -1,0 +1,140 @@
+"""Host-side mirror of the reference's renderer classes on top of the C ABI.
+
+``Surface`` and ``Raytracer`` carry the names and meaning of the reference's classes
+(/root/reference/surface.cs:7-19, MyApplication.cs:383-426): ``Raytracer(scene, camera,
+screen).Render()`` fills ``screen.pixels`` with 0x00RRGGBB ints, row 0 at the top.  The
+work is done by librt_hip.so through ``RenderContext``, a thin object wrapper over the
+entry points of include/rt_hip.h; errors surface as ``RtError`` carrying the library's
+message, the way the reference throws ``Exception(message)`` (template.cs:102-106).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import abi
+from .scene import Camera, FlatScene, Scene
+
+
+class RtError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{abi.STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+        self.message = message
+
+
+class RenderContext:
+    """One rt_ctx.  Not thread-safe: one caller thread per context, like the reference."""
+
+    def __init__(self, device_ids: Optional[Sequence[int]] = None):
+        self._lib = abi.load_library()
+        self._ctx = C.c_void_p()
+        ids = None
+        n = 0
+        if device_ids:
+            n = len(device_ids)
+            ids = (C.c_int * n)(*device_ids)
+        rc = self._lib.rt_create(C.byref(self._ctx), ids, n)
+        if rc != abi.RT_OK:
+            raise RtError(rc, self._lib.rt_last_error(None).decode())
+        self._scene_keepalive = None
+
+    # -- plumbing ---------------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != abi.RT_OK:
+            raise RtError(rc, self._lib.rt_last_error(self._ctx).decode())
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.rt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- ABI calls --------------------------------------------------------------------
+    def set_scene(self, flat: FlatScene) -> None:
+        self._check(self._lib.rt_set_scene(self._ctx, C.byref(flat.as_struct())))
+
+    def set_texture(self, slot: int, rgba8: np.ndarray) -> None:
+        img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        if img.ndim != 3 or img.shape[2] != 4:
+            raise ValueError("texture must be an HxWx4 uint8 array (R,G,B,A)")
+        self._check(self._lib.rt_set_texture(self._ctx, slot, img.ctypes.data, img.shape[1],
+                                             img.shape[0]))
+
+    def set_profiling(self, enable: bool) -> None:
+        self._check(self._lib.rt_set_profiling(self._ctx, 1 if enable else 0))
+
+    def render(self, camera: Camera, width: int, height: int,
+               max_depth: int = abi.RT_REFERENCE_MAX_DEPTH,
+               out: Optional[np.ndarray] = None) -> np.ndarray:
+        """rt_render: returns (or fills) an int32 [height, width] array in host memory."""
+        if out is None:
+            out = np.empty((height, width), dtype=np.int32)
+        if out.dtype != np.int32 or out.size != width * height or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous int32 array of width*height elements")
+        self._check(self._lib.rt_render(self._ctx, C.byref(camera.as_struct()), width, height,
+                                        max_depth, out.ctypes.data))
+        return out
+
+    def render_rows_device(self, camera: Camera, width: int, height: int, row_begin: int,
+                           row_end: int, max_depth: int, dev_ptr: int, stream: int = 0) -> None:
+        """rt_render_rows_device: dev_ptr is a device address of (row_end-row_begin)*width
+        int32 (e.g. ``tensor.data_ptr()``), stream a hipStream_t handle or 0."""
+        self._check(self._lib.rt_render_rows_device(
+            self._ctx, C.byref(camera.as_struct()), width, height, row_begin, row_end, max_depth,
+            C.c_void_p(dev_ptr), C.c_void_p(stream)))
+
+    def stats(self) -> dict:
+        st = abi.rt_stats()
+        self._check(self._lib.rt_get_stats(self._ctx, C.byref(st)))
+        return {name: getattr(st, name) for name, _ in st._fields_ if name != "reserved"}
+
+
+class Surface:
+    """surface.cs:7-19: a width x height int framebuffer, allocated once."""
+
+    def __init__(self, width: int, height: int):
+        self.width, self.height = int(width), int(height)
+        self.pixels = np.zeros(self.width * self.height, dtype=np.int32)
+
+    def Clear(self, c: int) -> None:  # surface.cs:42-45
+        self.pixels[:] = c
+
+    def image(self) -> np.ndarray:
+        return self.pixels.reshape(self.height, self.width)
+
+
+class Raytracer:
+    """MyApplication.cs:383-426 with Render() running on the GPU."""
+
+    def __init__(self, scene: Scene, camera: Camera, screen: Surface,
+                 device_ids: Optional[Sequence[int]] = None, textures: Sequence[np.ndarray] = (),
+                 max_depth: int = abi.RT_REFERENCE_MAX_DEPTH):
+        self.scene, self.camera, self.screen = scene, camera, screen
+        self.max_depth = max_depth
+        self.context = RenderContext(device_ids)
+        for slot, tex in enumerate(textures):
+            self.context.set_texture(slot, tex)
+        self.UpdateScene()
+
+    def UpdateScene(self) -> None:
+        """Re-flatten the scene after the host edited it (the reference reads its object
+        graph live; the library works on a copy)."""
+        self.context.set_scene(self.scene.flatten())
+
+    def Render(self) -> None:
+        self.context.render(self.camera, self.screen.width, self.screen.height, self.max_depth,
+                            out=self.screen.pixels)

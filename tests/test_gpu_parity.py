@@ -1,0 +1,167 @@
+"""GPU parity: librt_hip.so (through the C ABI) against the CPU oracle, same inputs."""
+import numpy as np
+import pytest
+
+from raytracer_amd import (Camera, Light, Material, Plane, RenderContext, RtError, Scene, Sphere,
+                           Triangle, default_scene, scene_1k, synthetic_scene)
+from tests.parity import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = RenderContext()
+    yield c
+    c.close()
+
+
+def both(ctx, oracle, scene, cam, w, h, depth, textures=None):
+    fs = scene.flatten() if isinstance(scene, Scene) else scene
+    if textures:
+        for i, t in enumerate(textures):
+            ctx.set_texture(i, t)
+    ctx.set_scene(fs)
+    gpu = ctx.render(cam, w, h, depth)
+    ref, counters = oracle.render(fs, cam, w, h, max_depth=depth, textures=textures)
+    return gpu, ref, counters
+
+
+def test_default_scene_template_resolution(ctx, oracle):
+    """Config 1: the reference's default scene (cyan wall) at 1080x1080, depth 5."""
+    gpu, ref, cnt = both(ctx, oracle, default_scene(), Camera(), 1080, 1080, 5)
+    r = assert_parity(gpu, ref, "default 1080x1080")
+    assert gpu[540, 540] == ref[540, 540] == 0x3E5A72
+    st = ctx.stats()
+    assert st["rays_primary"] == cnt["rays_primary"] == 1080 * 1080
+    assert st["rays_shadow"] == cnt["rays_shadow"]
+    assert st["rays_secondary"] == cnt["rays_secondary"]
+    assert st["shaded_hits"] == cnt["shaded_hits"]
+    assert st["sphere_tests"] == cnt["sphere_tests"]
+    assert st["plane_tests"] == cnt["plane_tests"]
+    assert st["triangle_tests"] == cnt["triangle_tests"]
+    assert r["max_diff"] <= 1
+
+
+def test_default_scene_textured_wall(ctx, oracle, wall_texture):
+    gpu, ref, _ = both(ctx, oracle, default_scene(textured_wall=True), Camera(), 1080, 1080, 5,
+                       textures=[wall_texture])
+    assert_parity(gpu, ref, "textured 1080x1080")
+
+
+def test_config2_1920x1080_primary_and_shadow_only(ctx, oracle):
+    """Config 2: 16:9 (horizontal half-angle fov*aspect/2), recursion disabled."""
+    gpu, ref, cnt = both(ctx, oracle, default_scene(), Camera(), 1920, 1080, 0)
+    assert_parity(gpu, ref, "default 1920x1080 depth 0")
+    assert cnt["rays_secondary"] == 0 and ctx.stats()["rays_secondary"] == 0
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2, 4, 8])
+def test_1k_spheres_depths(ctx, oracle, depth):
+    """Config 3's scene (1000 spheres + box) at a size the oracle finishes in seconds."""
+    gpu, ref, cnt = both(ctx, oracle, scene_1k(), Camera(), 480, 270, depth)
+    assert_parity(gpu, ref, f"1k spheres depth {depth}")
+    st = ctx.stats()
+    for k in ("rays_shadow", "rays_secondary", "shaded_hits", "sphere_tests", "plane_tests"):
+        assert st[k] == cnt[k], k
+
+
+def test_ragged_sizes_and_single_pixel(ctx, oracle):
+    for (w, h) in [(1, 1), (17, 9), (333, 127), (64, 1), (1, 64)]:
+        gpu, ref, _ = both(ctx, oracle, default_scene(), Camera(), w, h, 5)
+        assert np.array_equal(gpu, ref), (w, h)
+
+
+def test_moved_and_rotated_camera(ctx, oracle):
+    cams = [
+        Camera(position=(0.3, -0.2, 0.5), direction=(0.0, 0.0, 1.0)),
+        Camera(position=(-1.0, 0.2, 1.0), direction=(0.6, 0.0, 0.8), fov=70.0),
+        Camera(position=(0.0, 0.0, 2.0), direction=(0.0, 0.0, 1.0)),  # inside the mirror sphere
+        Camera(position=(1.0, -2.0, 3.0), direction=(-0.36, 0.48, -0.8), up=(0.0, 1.0, 0.0), fov=120.0),
+    ]
+    for cam in cams:
+        gpu, ref, _ = both(ctx, oracle, default_scene(), cam, 320, 200, 5)
+        assert_parity(gpu, ref, f"camera {cam}")
+
+
+def test_many_lights_use_several_mask_words(ctx, oracle):
+    s = synthetic_scene(40, seed=7)
+    s.lights.clear()
+    for i in range(37):
+        s.Add(Light(-3.0 + 0.16 * i, -1.0 + 0.01 * i, 0.4 + 0.07 * i))
+    gpu, ref, cnt = both(ctx, oracle, s, Camera(), 160, 120, 3)
+    assert_parity(gpu, ref, "37 lights")
+    assert ctx.stats()["rays_shadow"] == cnt["rays_shadow"]
+
+
+@pytest.mark.parametrize("nl", [0, 1, 3, 5, 16])
+def test_light_counts(ctx, oracle, nl):
+    s = synthetic_scene(30, seed=11)
+    s.lights.clear()
+    for i in range(nl):
+        s.Add(Light(-2.0 + 0.5 * i, -1.0, 0.5 + 0.2 * i))
+    gpu, ref, _ = both(ctx, oracle, s, Camera(), 128, 96, 4)
+    assert_parity(gpu, ref, f"{nl} lights")
+
+
+def test_empty_scene_and_miss(ctx, oracle):
+    s = Scene()
+    s.Add(Light(0, 0, 0))
+    gpu, ref, _ = both(ctx, oracle, s, Camera(), 40, 30, 5)
+    assert not gpu.any() and np.array_equal(gpu, ref)
+    # one small sphere: most primary rays miss and must write 0
+    s.Add(Sphere(0.0, 0.0, 3.0, 0.4, Material(1.0)))
+    gpu, ref, _ = both(ctx, oracle, s, Camera(), 200, 200, 5)
+    assert np.array_equal(gpu, ref) and gpu.any() and (gpu == 0).any()
+
+
+def test_ties_lowest_index_wins(ctx, oracle):
+    """Coincident primitives of different classes and colours: the first one added wins."""
+    red = Material(1.0, diffuseColor=(1, 0, 0, 1), ambientColor=(0.2, 0, 0, 1))
+    blue = Material(1.0, diffuseColor=(0, 0, 1, 1), ambientColor=(0, 0, 0.2, 1))
+    for order in (0, 1):
+        s = Scene()
+        tri = Triangle((-5.0, -5.0, 3.0), (5.0, -5.0, 3.0), (0.0, 5.0, 3.0), red)
+        pl = Plane(0.0, 0.0, -1.0, 3.0, blue)
+        for p in ((tri, pl) if order == 0 else (pl, tri)):
+            s.Add(p)
+        s.Add(Sphere(0.0, 0.0, 2.0, 0.25, blue if order == 0 else red))
+        s.Add(Sphere(0.0, 0.0, 2.0, 0.25, red if order == 0 else blue))
+        s.Add(Light(0.0, 0.0, 0.0))
+        gpu, ref, _ = both(ctx, oracle, s, Camera(), 96, 96, 2)
+        assert np.array_equal(gpu, ref), order
+
+
+def test_row_ranges_tile_the_frame(ctx, oracle):
+    import torch
+    fs = scene_1k().flatten()
+    ctx.set_scene(fs)
+    cam, w, h, depth = Camera(), 200, 120, 3
+    full = ctx.render(cam, w, h, depth)
+    pieces = []
+    for (y0, y1) in [(0, 37), (37, 38), (38, 120)]:
+        buf = torch.empty((y1 - y0, w), dtype=torch.int32, device="cuda")
+        ctx.render_rows_device(cam, w, h, y0, y1, depth, buf.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        pieces.append(buf.cpu().numpy())
+    assert np.array_equal(np.concatenate(pieces, axis=0), full)
+    ref, _ = oracle.render(fs, cam, w, h, max_depth=depth)
+    assert_parity(full, ref, "row ranges")
+
+
+def test_errors_follow_the_convention(ctx):
+    fresh = RenderContext()
+    with pytest.raises(RtError) as e:
+        fresh.render(Camera(), 8, 8, 5)
+    assert e.value.status == -5 and "rt_set_scene" in e.value.message
+    fresh.set_scene(default_scene(textured_wall=True).flatten())
+    with pytest.raises(RtError) as e:
+        fresh.render(Camera(), 8, 8, 5)
+    assert e.value.status == -6
+    fresh.set_scene(default_scene().flatten())
+    with pytest.raises(RtError):
+        fresh.render(Camera(), 0, 8, 5)
+    with pytest.raises(RtError):
+        fresh.render(Camera(), 8, 8, 99)
+    fresh.close()
