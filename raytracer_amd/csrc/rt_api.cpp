@@ -30,6 +30,7 @@ struct DeviceState {
     DevScene scene{};
     std::vector<void *> scene_allocs;
     float4 *sph_cam = nullptr;
+    float *sph_cam_c = nullptr;
     void *tex_mem[RT_MAX_TEXTURES] = {};
 
     // per-frame scratch
@@ -89,7 +90,9 @@ void free_scene(DeviceState &d)
     for (void *p : d.scene_allocs) (void)hipFree(p);
     d.scene_allocs.clear();
     if (d.sph_cam) (void)hipFree(d.sph_cam);
+    if (d.sph_cam_c) (void)hipFree(d.sph_cam_c);
     d.sph_cam = nullptr;
+    d.sph_cam_c = nullptr;
     const uchar4 *tex[RT_DEV_MAX_TEXTURES];
     int tw[RT_DEV_MAX_TEXTURES], th[RT_DEV_MAX_TEXTURES];
     memcpy(tex, d.scene.tex, sizeof tex);
@@ -135,6 +138,7 @@ struct PackedScene {
     std::vector<float4> sph, pl, tri, geo, mat, light_pos, light_col;
     std::vector<int> sph_orig, pl_orig, tri_orig, class_prefix;
     uint32_t textures_used = 0;
+    float sph_l1max = 0.f;
 };
 
 int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
@@ -158,6 +162,7 @@ int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
             const float r = s->prim_radius[i];
             out.sph.push_back(make_float4(p[0], p[1], p[2], r * r));  // objects.cs:114 radius*radius
             out.sph_orig.push_back(i);
+            out.sph_l1max = std::max(out.sph_l1max, std::fabs(p[0]) + std::fabs(p[1]) + std::fabs(p[2]));
             g = make_float4(p[0], p[1], p[2], 0.f);
             cs++;
         } else if (type == RT_PRIM_PLANE) {
@@ -237,7 +242,10 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     if ((rc = upload(ctx, d, ps.light_col, &sc.light_col)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.class_prefix, &sc.class_prefix)) != RT_OK) return rc;
     HIP_TRY(ctx, hipMalloc((void **)&d.sph_cam, std::max<size_t>(ps.sph.size() * sizeof(float4), 16)));
+    HIP_TRY(ctx, hipMalloc((void **)&d.sph_cam_c, std::max<size_t>(ps.sph.size() * sizeof(float), 16)));
     sc.sph_cam = d.sph_cam;
+    sc.sph_cam_c = d.sph_cam_c;
+    sc.sph_l1max = ps.sph_l1max;
     return RT_OK;
 }
 
@@ -348,10 +356,10 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, sizeof(DevCounters), stream));
     d.timed = ctx->profiling && stream == d.stream;
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
-    rtk_setup_camera(d.scene, dc, d.sph_cam, stream);
-    rtk_primary(d.scene, dc, f, dev_pixels, stream);
-    if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[1], stream));
     const int blocks = std::max(1, std::min((P + 255) / 256, d.num_cus * 8));
+    rtk_setup_camera(d.scene, dc, d.sph_cam, d.sph_cam_c, stream);
+    rtk_primary(d.scene, dc, f, dev_pixels, blocks, stream);
+    if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[1], stream));
     for (int k = 0; k <= max_depth; k++) rtk_trace_level(d.scene, f, k, blocks, stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[2], stream));
     for (int k = max_depth; k >= 0; k--) rtk_shade_level(d.scene, f, k, dev_pixels, blocks, stream);

@@ -5,15 +5,18 @@
 // host's insertion order; *_orig maps back to the host's primitive index, which is
 // what decides ties in closest-hit, MyApplication.cs:361):
 //   sph      float4 {cx, cy, cz, r*r}        one per sphere
-//   sph_cam  float4 {ox-cx, oy-cy, oz-cz, c} per frame, c = |o-p|^2 - r*r for the
-//                                            camera origin o (objects.cs:113-114)
+//   sph_cam  float4 {ox-cx, oy-cy, oz-cz, c''} per frame for the camera origin o; c'' is
+//                                            the sphere filter's constant (rt_kernels.hip)
+//   sph_cam_c float  c = |o-p|^2 - r*r       per frame, exact (objects.cs:113-114)
 //   pl       float4 {nx, ny, nz, d}          one per plane
 //   tri      float4 x3 {v0}, {e1}, {e2}      e1 = v1-v0, e2 = v2-v0 (objects.cs:238-239)
 //   geo      float4 per host primitive: sphere centre or plane/triangle normal
 //   mat      float4 x3 per host primitive: {diffuse.rgb, specular},
 //            {glossy.rgb, flags}, {ambient.rgb, -}
 //   light_pos / light_col  float4 per light
-// All of it is wave-uniform in every kernel, so it is read through the scalar cache.
+// The sphere arrays are staged in LDS by each workgroup and read from there into VGPRs
+// (one ds_read_b128 per sphere per wave, all lanes the same address); the small arrays
+// (planes, triangles, lights) are wave-uniform and read through the scalar cache.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -29,13 +32,15 @@
 
 // sph, sph_cam and sph_orig are padded to a multiple of RT_SPH_PAD entries; the padding
 // is {0, 0, 0, -inf}, which makes c = +inf so that no ray passes the sphere filter.
-#define RT_SPH_PAD 4
+#define RT_SPH_PAD 8
 
 struct DevScene {
     int ns, np, nt, nl, nprims;
     int ns_padded;
+    float sph_l1max;          // max over spheres of |cx| + |cy| + |cz| (bound used by the filter)
     const float4 *sph;
-    const float4 *sph_cam;
+    const float4 *sph_cam;    // per frame: {o-p, filter constant} for the camera origin
+    const float *sph_cam_c;   // per frame: exact c = |o-p|^2 - r*r for the camera origin
     const int *sph_orig;
     const float4 *pl;
     const int *pl_orig;
@@ -98,9 +103,10 @@ struct DevFrame {
 };
 
 // Launch wrappers (rt_kernels.hip).  All enqueue on `stream` and return at once.
-void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, hipStream_t stream);
+void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, float *sph_cam_c,
+                      hipStream_t stream);
 void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels,
-                 hipStream_t stream);
+                 int grid_blocks, hipStream_t stream);
 void rtk_trace_level(const DevScene &s, const DevFrame &f, int level, int grid_blocks,
                      hipStream_t stream);
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,

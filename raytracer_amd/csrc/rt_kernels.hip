@@ -1,13 +1,15 @@
 // rt_kernels.hip — gfx950 kernels of the render loop.
 //
-// Arithmetic contract: every FP32 expression is evaluated operation by operation in
-// the order the reference's C# evaluates it (no FMA contraction: this file is built
-// with -ffp-contract=off; IEEE divide and square root), and double precision is used
-// exactly where the reference calls System.Math (sin, pow).  Rearrangements below are
-// limited to ones that are exact in IEEE arithmetic and each says why.
+// Arithmetic contract: every value that can reach a pixel is evaluated operation by
+// operation in the order the reference's C# evaluates it (no FMA contraction: this file
+// is built with -ffp-contract=off; IEEE divide and square root), and double precision is
+// used exactly where the reference calls System.Math (sin, pow).  The one place that
+// departs from it is the sphere FILTER below, which only decides which (ray, sphere) pairs
+// get the exact evaluation; it is proven to let through every pair the exact evaluation
+// could accept, so it cannot change a result.
 //
 // Pipeline per frame (one HIP stream, in order):
-//   setup_camera   per sphere: o-p and c for the camera origin (shared by all pixels)
+//   setup_camera   per sphere: o-p and the filter constant for the camera origin
 //   primary        per pixel: ray direction, closest hit -> level-0 hit record
 //   trace_level k  per hit record: its light rays (any-hit) and, if the surface is
 //                  specular and k < max_depth, its reflection ray (closest hit) walk the
@@ -16,13 +18,20 @@
 //                  the colour goes to the parent record or, at level 0, to the pixel
 // The per-pixel bounce stack lives in HBM as compacted per-level queues (rt_device.h),
 // so every wave of every level is dense whatever the neighbouring pixels do.
+//
+// Instruction selection follows what the chip measures (tools/valu_issue_bench.hip):
+// v_mul/add/sub/fma_f32 and v_and/or_b32 with VGPR-only operands issue every ~2.1 cycles
+// per wave; the same instructions with an SGPR operand, every v_pk_*_f32, v_cmp_*,
+// v_min/max_f32 and v_max3_f32 take ~4.1.  Hence: sphere data is staged in LDS and read
+// into VGPRs (ds_read_b128, all lanes one address) instead of being used from SGPRs, the
+// filter is plain FMAs, and its verdicts are combined with integer AND/OR on sign bits.
 #include "rt_device.h"
 
 #include <limits.h>
 
 #define RT_EPS 0.0001f
 #define RT_FLT_MAX 3.40282347e+38f
-#define SPH_BATCH RT_SPH_PAD
+#define SPH_BATCH 4   // RT_SPH_PAD = 2 * SPH_BATCH
 
 // ---------------------------------------------------------------------------------------
 // OpenTK.Mathematics Vector3 operators, restated (Dot / Cross / Length / Normalized).
@@ -30,6 +39,22 @@
 struct f3 {
     float x, y, z;
 };
+// Scene arrays are read through the constant address space: their addresses are
+// wave-uniform and no kernel writes them while it reads them, so the loads become scalar
+// loads (s_load_dwordx4..x16 into SGPRs, broadcast to the lanes for free) even in loops that
+// also store to other buffers, where the compiler could not otherwise prove them unclobbered.
+typedef float f4raw __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) f4raw *const_f4_ptr;
+typedef const __attribute__((address_space(4))) int *const_int_ptr;
+__device__ __forceinline__ float4 cload(const float4 *p, int i)
+{
+    const f4raw v = ((const_f4_ptr)(unsigned long long)p)[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int cload(const int *p, int i) { return ((const_int_ptr)(unsigned long long)p)[i]; }
+typedef const __attribute__((address_space(4))) float *const_float_ptr;
+__device__ __forceinline__ float cload(const float *p, int i) { return ((const_float_ptr)(unsigned long long)p)[i]; }
+
 // IEEE-754 correctly rounded FP32 divide and square root.  Plain `/` and sqrtf() are
 // that under -fhip-fp32-correctly-rounded-divide-sqrt (set explicitly by the build);
 // the __fdiv_rn / __fsqrt_rn intrinsics are NOT (they map to the 1-ulp native forms).
@@ -157,7 +182,7 @@ __device__ __forceinline__ int wave_append(int *counter, bool flag)
 
 __device__ __forceinline__ bool material_specular_nonzero(const DevScene &s, int prim)
 {
-    return s.mat[3 * prim].w != 0.0f;
+    return cload(s.mat, 3 * prim).w != 0.0f;
 }
 
 // Write a new hit record of level `level` and return nothing; all lanes call it.
@@ -181,30 +206,102 @@ __device__ __forceinline__ void push_record(const DevFrame &f, const DevScene &s
 // setup_camera: per sphere, the terms of Sphere.Intersect that depend only on the ray
 // origin (objects.cs:113-114).  Every primary ray starts at camera.position, so they
 // are computed once per frame instead of once per pixel; same operations, same bits.
+// sph_cam[i] = {o-p, filter constant c''}, sph_cam_c[i] = exact c.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam, float4 *sph_cam)
+__global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam, float4 *sph_cam, float *sph_cam_c)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= s.ns_padded) return;  // padding: c = |o|^2 - (-inf) = +inf
-    float4 sp = s.sph[i];
-    f3 op = sub3(mk3(cam.pos[0], cam.pos[1], cam.pos[2]), xyz(sp));
-    float c = dot3(op, op) - sp.w;
-    sph_cam[i] = make_float4(op.x, op.y, op.z, c);
+    if (i >= s.ns_padded) return;
+    const float4 sp = s.sph[i];
+    const f3 op = sub3(mk3(cam.pos[0], cam.pos[1], cam.pos[2]), xyz(sp));
+    // Exact c of objects.cs:114 for the exact pass (padding: |o|^2 - (-inf) = +inf) ...
+    sph_cam_c[i] = dot3(op, op) - sp.w;
+    // ... and the filter's c'' (see "Sphere filter" below; padding: +inf as well).
+    const float q = __builtin_fmaf(op.z, op.z, __builtin_fmaf(op.y, op.y, op.x * op.x));
+    sph_cam[i] = make_float4(op.x, op.y, op.z, __builtin_fmaf(q, 0.999996185302734375f, -sp.w));
 }
 
 // ---------------------------------------------------------------------------------------
-// primary: Raytracer.Render's loop body up to scene.Intersect (MyApplication.cs:412-415)
-// plus GetRayDirection (:428-452).  One lane per pixel, 8x8 pixels per wave.
+// Sphere filter.
+//
+// For a ray (o, d) and a sphere (p, r) the reference computes, in FP32 without contraction
+// (objects.cs:112-121):  a = d.d,  x = d.(o-p),  c = (o-p).(o-p) - r*r,  disc = 4(x*x - a*c),
+// and only a pair with disc >= 0 and x < 0 can produce t > epsilon.  The filter evaluates
+// the same quantities with FMAs (3 + 1 instead of 5 + 3 operations per ray) and makes up
+// for the different rounding with two margins, u = 2^-24:
+//   x' = fma(-dz, opz, fma(-dy, opy, fma(-dx, opx, fm))),  fm = 16u * B1,
+//        B1 = |o|_1 + max_j |p_j|_1 >= |o - p|:  both evaluations of d.(o-p) are within
+//        3u|d||o-p| of the true value, so  x_ref < 0  implies  x' >= |x_ref| >= 0;
+//   c'' = fma(q, 1 - 64u, -r*r),  q = fma-evaluated |o-p|^2:  disc_ref >= 0 implies
+//        x_ref^2 >= q - r*r - 17u*q (a >= 1 - 6u for a normalised d, three roundings in c,
+//        one in each product), and c'' <= q - r*r - 62u*q, so  x'^2 - c'' >= 0.
+// A pair passes when  v = fma(x', x', -c'')  and  x'  both have a clear sign bit, i.e. when
+// (bits(v) | bits(x')) >= 0 as an integer.  Per sphere the verdicts of all rays are ANDed;
+// a sphere whose combined word is >= 0 in any lane goes to the exact code, which repeats
+// the reference's evaluation literally (sphere_maybe / sphere_root).  NaNs and infinities
+// can only add spurious passes, never remove one; padding entries (r*r = -inf) give
+// c'' = +inf, v = -inf and never pass.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevFrame f, int32_t *pixels)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = cam.row_begin + blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = x < cam.width && y < cam.row_end;
-    // Lanes outside the frame trace the frame's last pixel and write nothing.
-    const int px = inside ? x : cam.width - 1, py = inside ? y : cam.row_end - 1;
+#define FILTER_K1 0.999996185302734375f      // 1 - 2^-18 = 1 - 64u
+#define FILTER_FM_SCALE 9.5367431640625e-07f // 2^-20   = 16u
 
+// Spheres staged per workgroup: SPH_CHUNK entries of {cx, cy, cz, r*r} (or, for the primary
+// kernel, {ox-cx, oy-cy, oz-cz, c''}) plus SPH_BATCH entries of slack for the read-ahead.
+#define SPH_CHUNK 1024
+
+__device__ __forceinline__ void stage_spheres(float4 *lds, const float4 *src, int base, int count)
+{
+    for (int i = threadIdx.x; i < count; i += blockDim.x) lds[i] = src[base + i];
+    if (threadIdx.x < SPH_BATCH) lds[count + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ int filter_ray(f3 dn, float fm, f3 op, float c2)
+{
+    const float x = __builtin_fmaf(dn.z, op.z, __builtin_fmaf(dn.y, op.y, __builtin_fmaf(dn.x, op.x, fm)));
+    const float v = __builtin_fmaf(x, x, -c2);
+    return __float_as_int(v) | __float_as_int(x);
+}
+
+// The filter for NS spheres x NK rays, written stage by stage so that consecutive
+// instructions belong to different (sphere, ray) pairs: a wave's next instruction then never
+// waits for the previous one (a dependent FMA cannot issue back to back).
+//   op[u]   o - p of sphere u          c2[u]  its filter constant
+//   dn[k]   -d of ray k                out[u] AND over the rays of (bits(v) | bits(x'))
+template <int NS, int NK>
+__device__ __forceinline__ void filter_block(const f3 (&dn)[NK], const float fm, const f3 (&op)[NS],
+                                             const float (&c2)[NS], int (&out)[NS])
+{
+    float x[NS][NK];
+#pragma unroll
+    for (int u = 0; u < NS; u++)
+#pragma unroll
+        for (int k = 0; k < NK; k++) x[u][k] = __builtin_fmaf(dn[k].x, op[u].x, fm);
+#pragma unroll
+    for (int u = 0; u < NS; u++)
+#pragma unroll
+        for (int k = 0; k < NK; k++) x[u][k] = __builtin_fmaf(dn[k].y, op[u].y, x[u][k]);
+#pragma unroll
+    for (int u = 0; u < NS; u++)
+#pragma unroll
+        for (int k = 0; k < NK; k++) x[u][k] = __builtin_fmaf(dn[k].z, op[u].z, x[u][k]);
+    int w[NS][NK];
+#pragma unroll
+    for (int u = 0; u < NS; u++)
+#pragma unroll
+        for (int k = 0; k < NK; k++)
+            w[u][k] = __float_as_int(__builtin_fmaf(x[u][k], x[u][k], -c2[u])) | __float_as_int(x[u][k]);
+#pragma unroll
+    for (int u = 0; u < NS; u++) {
+        int a = w[u][0];
+#pragma unroll
+        for (int k = 1; k < NK; k++) a &= w[u][k];
+        out[u] = a;
+    }
+}
+
+// GetRayDirection's per-pixel part, MyApplication.cs:438-449.
+__device__ __forceinline__ f3 primary_direction(const DevCamera &cam, int px, int py)
+{
     float sx = (ieee_div((float)px, (float)cam.width) * 2.0f) - 1.0f;
     float sy = (ieee_div((float)py, (float)cam.height) * 2.0f) - 1.0f;
     sx *= cam.tan_h;
@@ -212,71 +309,145 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
     const f3 cdir = mk3(cam.dir[0], cam.dir[1], cam.dir[2]);
     const f3 cup = mk3(cam.up[0], cam.up[1], cam.up[2]);
     const f3 cleft = mk3(cam.left[0], cam.left[1], cam.left[2]);
-    const f3 o = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
-    const f3 d = normalized3(add3(add3(cdir, scale3(cup, sy)), scale3(cleft, sx)));
-    const float a = dot3(d, d);
+    return normalized3(add3(add3(cdir, scale3(cup, sy)), scale3(cleft, sx)));
+}
 
-    // Spheres, SPH_BATCH at a time: the filter for the whole batch is straight-line code
-    // (one scalar load burst, no branch), and one branch per batch leads to the exact
-    // root computation for the few (lane, sphere) pairs that pass.  Strict `<` within the
-    // class keeps the first of equal distances.  The arrays are padded to a multiple of
-    // SPH_BATCH with entries no ray can pass (c = +inf).
-    float best_t = RT_FLT_MAX;
-    int best_i = -1;
+// ---------------------------------------------------------------------------------------
+// primary: Raytracer.Render's loop body up to scene.Intersect (MyApplication.cs:412-415)
+// plus GetRayDirection (:428-452).  Each lane owns a 2x2 pixel quad, a wave 16x16 pixels, a
+// workgroup 32x32: one LDS read of a sphere feeds four rays, which keeps the LDS pipe (one
+// ds_read_b128 per 4 cycles per CU) well below the VALU time it has to feed.  Workgroups
+// are persistent so the spheres are staged once per workgroup.
+// ---------------------------------------------------------------------------------------
+#define PRIM_PX 4   // pixels per lane (2x2)
+
+__global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevFrame f, int32_t *pixels)
+{
+    __shared__ float4 lds[SPH_CHUNK + SPH_BATCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rows = cam.row_end - cam.row_begin;
+    const int tiles_x = (cam.width + 31) >> 5, tiles_y = (rows + 31) >> 5;
+    const int ntiles = tiles_x * tiles_y;
     const int nsp = s.ns_padded;
-    for (int i = 0; i < nsp; i += SPH_BATCH) {
-        float xx[SPH_BATCH], cc[SPH_BATCH];
-        bool pass[SPH_BATCH];
-        bool any = false;
+    const bool single = nsp <= SPH_CHUNK;
+    const f3 o = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
+    const float fm = FILTER_FM_SCALE * (((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) + s.sph_l1max);
+    if (single) {
+        stage_spheres(lds, s.sph_cam, 0, nsp);
+        __syncthreads();
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x, ty = tile / tiles_x;
+        const int x0 = tx * 32 + (wave & 1) * 16 + (lane & 7) * 2;
+        const int y0 = cam.row_begin + ty * 32 + (wave >> 1) * 16 + (lane >> 3) * 2;
+        bool inside[PRIM_PX];
+        int px[PRIM_PX], py[PRIM_PX];
+        f3 d[PRIM_PX], dn[PRIM_PX];
+        float a[PRIM_PX], best_t[PRIM_PX];
+        int best_i[PRIM_PX];
 #pragma unroll
-        for (int u = 0; u < SPH_BATCH; u++) {
-            const float4 sc = s.sph_cam[i + u];
-            xx[u] = dot3(d, mk3(sc.x, sc.y, sc.z));
-            cc[u] = sc.w;
-            pass[u] = sphere_maybe(xx[u], a * sc.w);
-            any = any || pass[u];
+        for (int k = 0; k < PRIM_PX; k++) {
+            const int x = x0 + (k & 1), y = y0 + (k >> 1);
+            inside[k] = x < cam.width && y < cam.row_end;
+            // Pixels outside the frame trace the frame's last pixel and write nothing.
+            px[k] = x < cam.width ? x : cam.width - 1;
+            py[k] = y < cam.row_end ? y : cam.row_end - 1;
+            d[k] = primary_direction(cam, px[k], py[k]);
+            dn[k] = mk3(-d[k].x, -d[k].y, -d[k].z);
+            a[k] = dot3(d[k], d[k]);
+            best_t[k] = RT_FLT_MAX;   // strict `<` within the class keeps the first of equals
+            best_i[k] = -1;
         }
-        if (any) {
+        for (int base = 0; base < nsp; base += SPH_CHUNK) {
+            const int cnt = min(SPH_CHUNK, nsp - base);
+            if (!single) {
+                __syncthreads();
+                stage_spheres(lds, s.sph_cam, base, cnt);
+                __syncthreads();
+            }
+            // One batch: filter SPH_BATCH spheres in straight-line code, then one branch to
+            // the exact evaluation for the spheres some lane could hit.
+            auto batch = [&](const float4 (&sp)[SPH_BATCH], const int first) {
+                int pass[SPH_BATCH], all = -1;
+                f3 op[SPH_BATCH];
+                float c2[SPH_BATCH];
 #pragma unroll
-            for (int u = 0; u < SPH_BATCH; u++) {
-                float t;
-                if (pass[u] && sphere_root(xx[u], cc[u], a, t) && t < best_t && t > RT_EPS) {
-                    best_t = t;
-                    best_i = i + u;
+                for (int u = 0; u < SPH_BATCH; u++) {
+                    op[u] = xyz(sp[u]);
+                    c2[u] = sp[u].w;
                 }
+                filter_block<SPH_BATCH, PRIM_PX>(dn, fm, op, c2, pass);
+#pragma unroll
+                for (int u = 0; u < SPH_BATCH; u++) all &= pass[u];
+                if (all >= 0) {
+#pragma unroll
+                    for (int u = 0; u < SPH_BATCH; u++) {
+                        if (pass[u] >= 0) {
+                            // objects.cs:112-121 literally; c for the camera origin as setup_camera
+                            // stores it next to the filter constant.
+                            const float c = cload(s.sph_cam_c, first + u);
+#pragma unroll
+                            for (int k = 0; k < PRIM_PX; k++) {
+                                const float xx = dot3(d[k], xyz(sp[u]));
+                                float t;
+                                if (sphere_maybe(xx, a[k] * c) && sphere_root(xx, c, a[k], t) && t < best_t[k] &&
+                                    t > RT_EPS) {
+                                    best_t[k] = t;
+                                    best_i[k] = first + u;
+                                }
+                            }
+                        }
+                    }
+                }
+            };
+            // Two register sets in ping-pong: the LDS reads of one batch are in flight while
+            // the other is computed (cnt is a multiple of 2*SPH_BATCH; the array has a batch
+            // of slack behind it for the last read-ahead).
+            float4 s0[SPH_BATCH], s1[SPH_BATCH];
+#pragma unroll
+            for (int u = 0; u < SPH_BATCH; u++) s0[u] = lds[u];
+            for (int i = 0; i < cnt; i += 2 * SPH_BATCH) {
+#pragma unroll
+                for (int u = 0; u < SPH_BATCH; u++) s1[u] = lds[i + SPH_BATCH + u];
+                batch(s0, base + i);
+#pragma unroll
+                for (int u = 0; u < SPH_BATCH; u++) s0[u] = lds[i + 2 * SPH_BATCH + u];
+                batch(s1, base + i + SPH_BATCH);
             }
         }
+#pragma unroll
+        for (int k = 0; k < PRIM_PX; k++) {
+            Closest c;
+            c.t = best_t[k];
+            c.prim = best_i[k] >= 0 ? cload(s.sph_orig, best_i[k]) : INT_MAX;
+            for (int j = 0; j < s.np; j++) {
+                const float4 pl = cload(s.pl, j);
+                const f3 n = xyz(pl);
+                const float numer = (-dot3(n, o)) - pl.w;
+                float t;
+                if (plane_t(n, numer, d[k], t)) closest_offer(c, t, cload(s.pl_orig, j));
+            }
+            for (int j = 0; j < s.nt; j++) {
+                const f3 v0 = xyz(cload(s.tri, 3 * j)), e1 = xyz(cload(s.tri, 3 * j + 1)),
+                         e2 = xyz(cload(s.tri, 3 * j + 2));
+                float t;
+                if (triangle_t(e1, e2, sub3(o, v0), d[k], t)) closest_offer(c, t, cload(s.tri_orig, j));
+            }
+            const bool hit = inside[k] && c.prim != INT_MAX;
+            const int pix = (py[k] - cam.row_begin) * cam.width + px[k];
+            const f3 hp = add3(o, scale3(d[k], c.t));
+            push_record(f, s, 0, hit, hit ? c.prim : 0, hp, d[k], pix);
+            if (inside[k] && !hit) pixels[pix] = 0;  // MyApplication.cs:423
+        }
     }
-    Closest c;
-    c.t = best_t;
-    c.prim = best_i >= 0 ? s.sph_orig[best_i] : INT_MAX;
-
-    for (int j = 0; j < s.np; j++) {
-        const float4 pl = s.pl[j];
-        const f3 n = xyz(pl);
-        const float numer = (-dot3(n, o)) - pl.w;
-        float t;
-        if (plane_t(n, numer, d, t)) closest_offer(c, t, s.pl_orig[j]);
-    }
-    for (int j = 0; j < s.nt; j++) {
-        const f3 v0 = xyz(s.tri[3 * j]), e1 = xyz(s.tri[3 * j + 1]), e2 = xyz(s.tri[3 * j + 2]);
-        float t;
-        if (triangle_t(e1, e2, sub3(o, v0), d, t)) closest_offer(c, t, s.tri_orig[j]);
-    }
-
-    const bool hit = inside && c.prim != INT_MAX;
-    const int pix = (py - cam.row_begin) * cam.width + px;
-    const f3 hp = add3(o, scale3(d, c.t));
-    push_record(f, s, 0, hit, hit ? c.prim : 0, hp, d, pix);
-    if (inside && !hit) pixels[pix] = 0;  // MyApplication.cs:423
 }
 
 // ---------------------------------------------------------------------------------------
 // trace_level: for each hit record, IsInShadow towards every light (objects.cs:51-60)
 // and, for specular surfaces below the depth bound, scene.Intersect along the mirror
-// direction (objects.cs:82-83).  All of a record's rays start at its hit point, so
-// o-p, |o-p|^2 and c (objects.cs:113-114) are formed once per sphere and reused by
-// every ray of the record: NR rays cost 9 + 8*NR operations per sphere instead of 17*NR.
+// direction (objects.cs:82-83).  All of a record's rays start at its hit point, so o-p and
+// the filter constant are formed once per sphere and shared by the record's NR rays: a
+// sphere costs 7 + 6*NR full-rate instructions per lane.
 // ---------------------------------------------------------------------------------------
 template <int LC, bool SEC>
 struct Rays {
@@ -290,64 +461,96 @@ struct Rays {
 };
 
 template <int LC, bool SEC>
-__device__ __forceinline__ void traverse(const DevScene &s, const f3 o, Rays<LC, SEC> &r)
+__device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, const bool single, const f3 o,
+                                         Rays<LC, SEC> &r)
 {
-    // ---- spheres: batches of SPH_BATCH, filter in straight-line code, one branch -------
+    constexpr int NR = LC + (SEC ? 1 : 0);
+    f3 dn[NR > 0 ? NR : 1];
+#pragma unroll
+    for (int l = 0; l < LC; l++) dn[l] = mk3(-r.sh_d[l].x, -r.sh_d[l].y, -r.sh_d[l].z);
+    if (SEC) dn[LC] = mk3(-r.sec_d.x, -r.sec_d.y, -r.sec_d.z);
+    const float fm = FILTER_FM_SCALE * (((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) + s.sph_l1max);
+    // Kept in a VGPR: as an SGPR or literal operand it would halve the FMA's issue rate.
+    float k1 = FILTER_K1;
+    asm volatile("" : "+v"(k1));
+
     float best_t = RT_FLT_MAX;
     int best_i = -1;
     const int nsp = s.ns_padded;
-    constexpr int NR = LC + (SEC ? 1 : 0);
-    for (int i = 0; i < nsp; i += SPH_BATCH) {
-        float cc[SPH_BATCH], xr[SPH_BATCH][NR > 0 ? NR : 1];
-        bool pass[SPH_BATCH][NR > 0 ? NR : 1];
-        bool any = false;
-#pragma unroll
-        for (int u = 0; u < SPH_BATCH; u++) {
-            const float4 sp = s.sph[i + u];
-            const f3 op = sub3(o, xyz(sp));
-            cc[u] = dot3(op, op) - sp.w;
-            if (SEC) {
-                xr[u][LC] = dot3(r.sec_d, op);
-                pass[u][LC] = sphere_maybe(xr[u][LC], r.sec_a * cc[u]);
-                any = any || pass[u][LC];
-            }
-#pragma unroll
-            for (int l = 0; l < LC; l++) {
-                xr[u][l] = dot3(r.sh_d[l], op);
-                pass[u][l] = sphere_maybe(xr[u][l], r.sh_a[l] * cc[u]);
-                any = any || pass[u][l];
-            }
+    for (int base = 0; base < nsp; base += SPH_CHUNK) {
+        const int cnt = min(SPH_CHUNK, nsp - base);
+        if (!single) {
+            __syncthreads();
+            stage_spheres(lds, s.sph, base, cnt);
+            __syncthreads();
         }
-        if (any) {
+        auto batch = [&](const float4 (&sp)[SPH_BATCH], const int first) {
+            int pass[SPH_BATCH], all = -1;
+            f3 op[SPH_BATCH];
+            float q[SPH_BATCH], c2[SPH_BATCH];
 #pragma unroll
-            for (int u = 0; u < SPH_BATCH; u++) {
-                float t;
-                if (SEC) {
-                    if (pass[u][LC] && sphere_root(xr[u][LC], cc[u], r.sec_a, t) && t < best_t &&
-                        t > RT_EPS) {
-                        best_t = t;
-                        best_i = i + u;
+            for (int u = 0; u < SPH_BATCH; u++) op[u] = sub3(o, xyz(sp[u]));
+#pragma unroll
+            for (int u = 0; u < SPH_BATCH; u++) q[u] = op[u].x * op[u].x;
+#pragma unroll
+            for (int u = 0; u < SPH_BATCH; u++) q[u] = __builtin_fmaf(op[u].y, op[u].y, q[u]);
+#pragma unroll
+            for (int u = 0; u < SPH_BATCH; u++) q[u] = __builtin_fmaf(op[u].z, op[u].z, q[u]);
+#pragma unroll
+            for (int u = 0; u < SPH_BATCH; u++) c2[u] = __builtin_fmaf(q[u], k1, -sp[u].w);
+            filter_block<SPH_BATCH, (NR > 0 ? NR : 1)>(dn, fm, op, c2, pass);
+#pragma unroll
+            for (int u = 0; u < SPH_BATCH; u++) all &= pass[u];
+            if (all >= 0) {
+#pragma unroll
+                for (int u = 0; u < SPH_BATCH; u++) {
+                    if (pass[u] >= 0) {
+                        // Sphere.Intersect objects.cs:112-121, literally.
+                        const f3 op = sub3(o, xyz(sp[u]));
+                        const float c = dot3(op, op) - sp[u].w;
+                        float t;
+                        if (SEC) {
+                            const float x = dot3(r.sec_d, op);
+                            if (sphere_maybe(x, r.sec_a * c) && sphere_root(x, c, r.sec_a, t) && t < best_t &&
+                                t > RT_EPS) {
+                                best_t = t;
+                                best_i = first + u;
+                            }
+                        }
+#pragma unroll
+                        for (int l = 0; l < LC; l++) {
+                            const float x = dot3(r.sh_d[l], op);
+                            if (sphere_maybe(x, r.sh_a[l] * c) && sphere_root(x, c, r.sh_a[l], t) && t > RT_EPS &&
+                                t < r.sh_dist[l])
+                                r.sh_first[l] = min(r.sh_first[l], cload(s.sph_orig, first + u));
+                        }
                     }
                 }
-#pragma unroll
-                for (int l = 0; l < LC; l++) {
-                    if (pass[u][l] && sphere_root(xr[u][l], cc[u], r.sh_a[l], t) && t > RT_EPS &&
-                        t < r.sh_dist[l])
-                        r.sh_first[l] = min(r.sh_first[l], s.sph_orig[i + u]);
-                }
             }
+        };
+        // Ping-pong register sets, as in the primary kernel.
+        float4 s0[SPH_BATCH], s1[SPH_BATCH];
+#pragma unroll
+        for (int u = 0; u < SPH_BATCH; u++) s0[u] = lds[u];
+        for (int i = 0; i < cnt; i += 2 * SPH_BATCH) {
+#pragma unroll
+            for (int u = 0; u < SPH_BATCH; u++) s1[u] = lds[i + SPH_BATCH + u];
+            batch(s0, base + i);
+#pragma unroll
+            for (int u = 0; u < SPH_BATCH; u++) s0[u] = lds[i + 2 * SPH_BATCH + u];
+            batch(s1, base + i + SPH_BATCH);
         }
     }
     if (SEC) {
         r.sec.t = best_t;
-        r.sec.prim = best_i >= 0 ? s.sph_orig[best_i] : INT_MAX;
+        r.sec.prim = best_i >= 0 ? cload(s.sph_orig, best_i) : INT_MAX;
     }
     // ---- planes --------------------------------------------------------------------
     for (int j = 0; j < s.np; j++) {
-        const float4 pl = s.pl[j];
+        const float4 pl = cload(s.pl, j);
         const f3 n = xyz(pl);
         const float numer = (-dot3(n, o)) - pl.w;
-        const int orig = s.pl_orig[j];
+        const int orig = cload(s.pl_orig, j);
         float t;
         if (SEC) {
             if (plane_t(n, numer, r.sec_d, t)) closest_offer(r.sec, t, orig);
@@ -360,9 +563,9 @@ __device__ __forceinline__ void traverse(const DevScene &s, const f3 o, Rays<LC,
     }
     // ---- triangles -----------------------------------------------------------------
     for (int j = 0; j < s.nt; j++) {
-        const f3 v0 = xyz(s.tri[3 * j]), e1 = xyz(s.tri[3 * j + 1]), e2 = xyz(s.tri[3 * j + 2]);
+        const f3 v0 = xyz(cload(s.tri, 3 * j)), e1 = xyz(cload(s.tri, 3 * j + 1)), e2 = xyz(cload(s.tri, 3 * j + 2));
         const f3 sv = sub3(o, v0);
-        const int orig = s.tri_orig[j];
+        const int orig = cload(s.tri_orig, j);
         float t;
         if (SEC) {
             if (triangle_t(e1, e2, sv, r.sec_d, t)) closest_offer(r.sec, t, orig);
@@ -379,7 +582,7 @@ __device__ __forceinline__ void traverse(const DevScene &s, const f3 o, Rays<LC,
 // plane / triangle normal (objects.cs:171-174, 270-273).
 __device__ __forceinline__ f3 record_normal(const DevScene &s, int prim, int type, f3 hit)
 {
-    const float4 g = s.geo[prim];
+    const float4 g = cload(s.geo, prim);
     if (type == 0) return normalized3(sub3(hit, xyz(g)));
     return xyz(g);
 }
@@ -390,14 +593,14 @@ struct TestCount {
 
 // One chunk of LC lights (plus the reflection ray when SEC) for one record.
 template <int LC, bool SEC>
-__device__ __forceinline__ void trace_chunk(const DevScene &s, const f3 hit, const f3 view,
-                                            const f3 normal, int l0, uint32_t &mask_word,
+__device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, const bool single, const f3 hit,
+                                            const f3 view, const f3 normal, int l0, uint32_t &mask_word,
                                             Closest &sec_out, f3 &sec_dir, TestCount &tc)
 {
     Rays<LC, SEC> r;
 #pragma unroll
     for (int l = 0; l < LC; l++) {
-        const f3 lp = xyz(s.light_pos[l0 + l]);
+        const f3 lp = xyz(cload(s.light_pos, l0 + l));
         const f3 to_light = sub3(lp, hit);
         r.sh_d[l] = normalized3(to_light);          // objects.cs:51
         r.sh_dist[l] = length3(to_light);           // objects.cs:52
@@ -411,7 +614,7 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, const f3 hit, con
         r.sec.t = RT_FLT_MAX;
         r.sec.prim = INT_MAX;
     }
-    traverse<LC, SEC>(s, hit, r);
+    traverse<LC, SEC>(s, lds, single, hit, r);
 #pragma unroll
     for (int l = 0; l < LC; l++) {
         const bool occluded = r.sh_first[l] != INT_MAX;
@@ -419,9 +622,9 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, const f3 hit, con
         // Tests the reference executes for this light: primitives up to and including
         // the first occluder (MyApplication.cs:373-378), all of them when unoccluded.
         const int upto = occluded ? r.sh_first[l] + 1 : s.nprims;
-        tc.sph += s.class_prefix[3 * upto + 0];
-        tc.pl += s.class_prefix[3 * upto + 1];
-        tc.tri += s.class_prefix[3 * upto + 2];
+        tc.sph += cload(s.class_prefix, 3 * upto + 0);
+        tc.pl += cload(s.class_prefix, 3 * upto + 1);
+        tc.tri += cload(s.class_prefix, 3 * upto + 2);
     }
     if (SEC) {
         sec_out = r.sec;
@@ -432,22 +635,31 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, const f3 hit, con
     }
 }
 
-template <bool SEC>
+// SEC: the records of the level that need a reflection trace (queue "A") or the others
+// ("B").  LCMAX: lights handled per scene walk (2 or 4); with few lights the 2-light
+// instance is used, which needs far fewer registers.
+template <bool SEC, int LCMAX>
 __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level)
 {
+    __shared__ float4 lds[SPH_CHUNK + SPH_BATCH];
     const int n = SEC ? f.cnt[2 * level] : f.cnt[2 * level + 1];
-    const int lane_global = blockIdx.x * blockDim.x + threadIdx.x;
-    const int stride = gridDim.x * blockDim.x;
+    const int ntiles = (n + 255) >> 8;
+    const bool single = s.ns_padded <= SPH_CHUNK;
+    if (single && (int)blockIdx.x < ntiles) {
+        stage_spheres(lds, s.sph, 0, s.ns_padded);
+        __syncthreads();
+    }
     TestCount tc = {0, 0, 0};
-    for (int base = lane_global - (threadIdx.x & 63); base < n; base += stride) {
-        const int i = base + (threadIdx.x & 63);
+    // Workgroup-uniform trip count: the sphere chunks are staged between barriers.
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int i = tile * 256 + threadIdx.x;
         const bool active = i < n;
         const int ii = active ? i : n - 1;
         const int slot = SEC ? (level * f.P + ii) : ((level + 1) * f.P - 1 - ii);
         const float4 ra = f.recA[slot], rb = f.recB[slot];
         const f3 hit = xyz(ra), view = xyz(rb);
         const int prim = __float_as_int(ra.w);
-        const int type = __float_as_int(s.mat[3 * prim + 1].w) & RT_MF_TYPE_MASK;
+        const int type = __float_as_int(cload(s.mat, 3 * prim + 1).w) & RT_MF_TYPE_MASK;
         const f3 normal = record_normal(s, prim, type, hit);
 
         Closest sec = {RT_FLT_MAX, INT_MAX};
@@ -460,20 +672,20 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
         // Lights in chunks of 4 / 2 / 1; the reflection ray rides with the first chunk.
         while (l0 < nl || (SEC && first)) {
             const int rem = nl - l0;
-            if (rem >= 4) {
-                if (SEC && first) trace_chunk<4, true>(s, hit, view, normal, l0, word, sec, sec_dir, ltc);
-                else trace_chunk<4, false>(s, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            if (LCMAX >= 4 && rem >= 4) {
+                if (SEC && first) trace_chunk<LCMAX >= 4 ? 4 : 2, true>(s, lds, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                else trace_chunk<LCMAX >= 4 ? 4 : 2, false>(s, lds, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
                 l0 += 4;
             } else if (rem >= 2) {
-                if (SEC && first) trace_chunk<2, true>(s, hit, view, normal, l0, word, sec, sec_dir, ltc);
-                else trace_chunk<2, false>(s, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                if (SEC && first) trace_chunk<2, true>(s, lds, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                else trace_chunk<2, false>(s, lds, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
                 l0 += 2;
             } else if (rem == 1) {
-                if (SEC && first) trace_chunk<1, true>(s, hit, view, normal, l0, word, sec, sec_dir, ltc);
-                else trace_chunk<1, false>(s, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                if (SEC && first) trace_chunk<1, true>(s, lds, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                else trace_chunk<1, false>(s, lds, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
                 l0 += 1;
             } else {
-                trace_chunk<0, true>(s, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                trace_chunk<0, true>(s, lds, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
             }
             first = false;
             if (l0 > 0 && ((l0 & 31) == 0 || l0 >= nl)) {
@@ -559,7 +771,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
         const float4 ra = f.recA[slot], rb = f.recB[slot];
         const f3 hit = xyz(ra), view = xyz(rb);
         const int prim = __float_as_int(ra.w), parent = __float_as_int(rb.w);
-        const float4 m0 = s.mat[3 * prim], m1 = s.mat[3 * prim + 1], m2 = s.mat[3 * prim + 2];
+        const float4 m0 = cload(s.mat, 3 * prim), m1 = cload(s.mat, 3 * prim + 1), m2 = cload(s.mat, 3 * prim + 2);
         const int flags = __float_as_int(m1.w);
         const int type = flags & RT_MF_TYPE_MASK;
         const f3 normal = record_normal(s, prim, type, hit);
@@ -593,7 +805,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
         uint32_t word = 0;
         for (int l = 0; l < nl; l++) {
             if ((l & 31) == 0) word = f.mask[(size_t)(l >> 5) * (size_t)f.slots + slot];
-            const f3 lp = xyz(s.light_pos[l]), lc = xyz(s.light_col[l]);
+            const f3 lp = xyz(cload(s.light_pos, l)), lc = xyz(cload(s.light_col, l));
             const f3 to_light = sub3(lp, hit);
             const f3 shadow_ray = normalized3(to_light);
             const float distance = length3(to_light);
@@ -636,26 +848,34 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
 // ---------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------
-void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, hipStream_t stream)
+void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, float *sph_cam_c,
+                      hipStream_t stream)
 {
     if (s.ns_padded <= 0) return;
-    hipLaunchKernelGGL(k_setup_camera, dim3((s.ns_padded + 255) / 256), dim3(256), 0, stream, s, cam, sph_cam);
+    hipLaunchKernelGGL(k_setup_camera, dim3((s.ns_padded + 255) / 256), dim3(256), 0, stream, s, cam, sph_cam,
+                       sph_cam_c);
 }
 
-void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels,
+void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels, int grid_blocks,
                  hipStream_t stream)
 {
     const int rows = cam.row_end - cam.row_begin;
-    dim3 grid((cam.width + 15) / 16, (rows + 15) / 16);
-    hipLaunchKernelGGL(k_primary, grid, dim3(256), 0, stream, s, cam, f, pixels);
+    const int ntiles = ((cam.width + 31) / 32) * ((rows + 31) / 32);  // 32x32 pixels per workgroup trip
+    hipLaunchKernelGGL(k_primary, dim3(ntiles < grid_blocks ? ntiles : grid_blocks), dim3(256), 0, stream, s, cam, f,
+                       pixels);
 }
 
 void rtk_trace_level(const DevScene &s, const DevFrame &f, int level, int grid_blocks,
                      hipStream_t stream)
 {
-    if (level < f.max_depth)
-        hipLaunchKernelGGL(k_trace<true>, dim3(grid_blocks), dim3(256), 0, stream, s, f, level);
-    hipLaunchKernelGGL(k_trace<false>, dim3(grid_blocks), dim3(256), 0, stream, s, f, level);
+    const dim3 g(grid_blocks), b(256);
+    if (s.nl >= 4) {
+        if (level < f.max_depth) hipLaunchKernelGGL((k_trace<true, 4>), g, b, 0, stream, s, f, level);
+        hipLaunchKernelGGL((k_trace<false, 4>), g, b, 0, stream, s, f, level);
+    } else {
+        if (level < f.max_depth) hipLaunchKernelGGL((k_trace<true, 2>), g, b, 0, stream, s, f, level);
+        hipLaunchKernelGGL((k_trace<false, 2>), g, b, 0, stream, s, f, level);
+    }
 }
 
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
