@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "librt_hip.so")
 SOURCES = ["rt_api.cpp", "rt_kernels.hip"]
-HEADERS = ["rt_device.h", os.path.join("..", "..", "include", "rt_hip.h")]
+HEADERS = ["rt_device.h", "filter_asm.inc", os.path.join("..", "..", "include", "rt_hip.h")]
 
 # -ffp-contract=off and IEEE divide/sqrt are part of the numerical contract of the
 # library (bit-level agreement with a strict-FP32 evaluation), not tuning knobs.

@@ -652,6 +652,7 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out)
         out->sphere_tests += c.sphere_tests + P * (uint64_t)d.scene.ns;
         out->plane_tests += c.plane_tests + P * (uint64_t)d.scene.np;
         out->triangle_tests += c.triangle_tests + P * (uint64_t)d.scene.nt;
+        out->exact_batches += c.exact_batches;
         if (d.timed) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, d.ev[0], d.ev[3]) == hipSuccess) kernel_ms = std::max(kernel_ms, (double)ms);

@@ -76,7 +76,7 @@ struct DevCounters {
     unsigned long long sphere_tests;
     unsigned long long plane_tests;
     unsigned long long triangle_tests;
-    unsigned long long pad;
+    unsigned long long exact_batches;   // wave-level: 4-sphere batches sent to the exact code
 };
 
 // Hit records: the bounce stack of every pixel, kept in HBM.  Level k of the frame

@@ -26,11 +26,15 @@
 // into VGPRs (ds_read_b128, all lanes one address) instead of being used from SGPRs, the
 // filter is plain FMAs, and its verdicts are combined with integer AND/OR on sign bits.
 #include "rt_device.h"
+#include "filter_asm.inc"
 
 #include <limits.h>
 
 #define RT_EPS 0.0001f
 #define RT_FLT_MAX 3.40282347e+38f
+// Margins of the sphere filter (derivation: "Sphere filter" below); u = 2^-24.
+#define FILTER_K1 0.999996185302734375f      // 1 - 2^-18 = 1 - 64u
+#define FILTER_FM_SCALE 9.5367431640625e-07f // 2^-20   = 16u
 #define SPH_BATCH 4   // RT_SPH_PAD = 2 * SPH_BATCH
 
 // ---------------------------------------------------------------------------------------
@@ -165,48 +169,71 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
-// Append `flag` lanes to a counter with one atomic per wave; returns the lane's slot
-// offset (valid where flag).  All lanes of the wave must call it.
-__device__ __forceinline__ int wave_append(int *counter, bool flag)
-{
-    unsigned long long m = __ballot(flag);
-    int lane = threadIdx.x & 63;
-    int base = 0;
-    if (m != 0ull) {
-        int leader = __ffsll((long long)m) - 1;
-        if (lane == leader) base = atomicAdd(counter, __popcll(m));
-        base = __shfl(base, leader, 64);
-    }
-    return base + __popcll(m & ((1ull << lane) - 1ull));
-}
-
 __device__ __forceinline__ bool material_specular_nonzero(const DevScene &s, int prim)
 {
     return cload(s.mat, 3 * prim).w != 0.0f;
 }
 
-// Write a new hit record of level `level` and return nothing; all lanes call it.
-__device__ __forceinline__ void push_record(const DevFrame &f, const DevScene &s, int level,
-                                            bool valid, int prim, f3 hit, f3 view, int parent)
+// Append up to N new hit records per thread to level `level`, with ONE atomic per queue per
+// WORKGROUP: a single counter word takes only ~90 returning atomics per microsecond, and a
+// frame appends hundreds of thousands of waves' worth of records.  Every thread of the
+// workgroup must call it (two barriers inside); blk is a __shared__ int[12].
+//   A records (need a reflection trace) fill the level from the front, B records from the back.
+template <int N>
+__device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &s, int level, int *blk,
+                                             const bool (&valid)[N], const int (&prim)[N], const f3 (&hit)[N],
+                                             const f3 (&view)[N], const int (&parent)[N])
 {
-    // The reference traces the reflection inside its light loop (objects.cs:49,80-83):
-    // no lights, no trace.
-    bool needs_trace = valid && level < f.max_depth && s.nl > 0 && material_specular_nonzero(s, prim);
-    bool plain = valid && !needs_trace;
-    int ia = wave_append(&f.cnt[2 * level], needs_trace);
-    int ib = wave_append(&f.cnt[2 * level + 1], plain);
-    if (valid) {
-        int slot = needs_trace ? (level * f.P + ia) : ((level + 1) * f.P - 1 - ib);
-        f.recA[slot] = make_float4(hit.x, hit.y, hit.z, __int_as_float(prim));
-        f.recB[slot] = make_float4(view.x, view.y, view.z, __int_as_float(parent));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    bool is_a[N];
+    int off[N];
+    int wave_a = 0, wave_b = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        // The reference traces the reflection inside its light loop (objects.cs:49,80-83):
+        // no lights, no trace.
+        is_a[k] = valid[k] && level < f.max_depth && s.nl > 0 && material_specular_nonzero(s, prim[k]);
+        const unsigned long long ma = __ballot(is_a[k]), mb = __ballot(valid[k] && !is_a[k]);
+        off[k] = is_a[k] ? wave_a + __popcll(ma & below) : wave_b + __popcll(mb & below);
+        wave_a += __popcll(ma);
+        wave_b += __popcll(mb);
     }
+    if (lane == 0) {
+        blk[2 * wave] = wave_a;
+        blk[2 * wave + 1] = wave_b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ta = 0, tb = 0;
+        for (int w = 0; w < nwaves; w++) {
+            const int a = blk[2 * w], b = blk[2 * w + 1];
+            blk[2 * w] = ta;
+            blk[2 * w + 1] = tb;
+            ta += a;
+            tb += b;
+        }
+        blk[8] = ta ? atomicAdd(&f.cnt[2 * level], ta) : 0;
+        blk[9] = tb ? atomicAdd(&f.cnt[2 * level + 1], tb) : 0;
+    }
+    __syncthreads();
+    const int base_a = blk[8] + blk[2 * wave], base_b = blk[9] + blk[2 * wave + 1];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        if (valid[k]) {
+            const int slot = is_a[k] ? (level * f.P + base_a + off[k]) : ((level + 1) * f.P - 1 - (base_b + off[k]));
+            f.recA[slot] = make_float4(hit[k].x, hit[k].y, hit[k].z, __int_as_float(prim[k]));
+            f.recB[slot] = make_float4(view[k].x, view[k].y, view[k].z, __int_as_float(parent[k]));
+        }
+    }
+    __syncthreads();  // blk may be reused by the caller's next trip
 }
 
 // ---------------------------------------------------------------------------------------
 // setup_camera: per sphere, the terms of Sphere.Intersect that depend only on the ray
 // origin (objects.cs:113-114).  Every primary ray starts at camera.position, so they
 // are computed once per frame instead of once per pixel; same operations, same bits.
-// sph_cam[i] = {o-p, filter constant c''}, sph_cam_c[i] = exact c.
+// sph_cam[i] = {o-p, -c''} (c'' = the filter's constant), sph_cam_c[i] = exact c.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam, float4 *sph_cam, float *sph_cam_c)
 {
@@ -216,9 +243,9 @@ __global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam,
     const f3 op = sub3(mk3(cam.pos[0], cam.pos[1], cam.pos[2]), xyz(sp));
     // Exact c of objects.cs:114 for the exact pass (padding: |o|^2 - (-inf) = +inf) ...
     sph_cam_c[i] = dot3(op, op) - sp.w;
-    // ... and the filter's c'' (see "Sphere filter" below; padding: +inf as well).
+    // ... and the filter's -c'' (see "Sphere filter" below; padding: -inf, never passes).
     const float q = __builtin_fmaf(op.z, op.z, __builtin_fmaf(op.y, op.y, op.x * op.x));
-    sph_cam[i] = make_float4(op.x, op.y, op.z, __builtin_fmaf(q, 0.999996185302734375f, -sp.w));
+    sph_cam[i] = make_float4(op.x, op.y, op.z, -__builtin_fmaf(q, FILTER_K1, -sp.w));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -242,62 +269,32 @@ __global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam,
 // can only add spurious passes, never remove one; padding entries (r*r = -inf) give
 // c'' = +inf, v = -inf and never pass.
 // ---------------------------------------------------------------------------------------
-#define FILTER_K1 0.999996185302734375f      // 1 - 2^-18 = 1 - 64u
-#define FILTER_FM_SCALE 9.5367431640625e-07f // 2^-20   = 16u
+// The filter loops themselves are gfx950 assembly with a fixed, VGPR-bank-conflict-free
+// register plan (filter_asm.inc, generated by tools/gen_filter_asm.py): hipcc's register
+// allocation ignores banks, and a three-source instruction with two sources in one bank
+// issues at half rate.  A loop walks the spheres staged in LDS, four per batch, and returns
+// at the first batch in which some lane's ray could hit a sphere; the exact evaluation of
+// that batch happens here in C++, then the loop is re-entered behind it.
 
 // Spheres staged per workgroup: SPH_CHUNK entries of {cx, cy, cz, r*r} (or, for the primary
-// kernel, {ox-cx, oy-cy, oz-cz, c''}) plus SPH_BATCH entries of slack for the read-ahead.
+// kernel, {ox-cx, oy-cy, oz-cz, -c''}) plus FA_LDS_SLACK never-pass entries for the loops'
+// read-ahead.
 #define SPH_CHUNK 1024
+#define SPH_LDS_ENTRIES (SPH_CHUNK + FA_LDS_SLACK)
 
 __device__ __forceinline__ void stage_spheres(float4 *lds, const float4 *src, int base, int count)
 {
     for (int i = threadIdx.x; i < count; i += blockDim.x) lds[i] = src[base + i];
-    if (threadIdx.x < SPH_BATCH) lds[count + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x < FA_LDS_SLACK) lds[count + threadIdx.x] = make_float4(0.f, 0.f, 0.f, -INFINITY);
 }
 
-__device__ __forceinline__ int filter_ray(f3 dn, float fm, f3 op, float c2)
+// Byte offset of an LDS object inside the workgroup's LDS allocation (what ds_read takes).
+__device__ __forceinline__ unsigned lds_offset(const void *p)
 {
-    const float x = __builtin_fmaf(dn.z, op.z, __builtin_fmaf(dn.y, op.y, __builtin_fmaf(dn.x, op.x, fm)));
-    const float v = __builtin_fmaf(x, x, -c2);
-    return __float_as_int(v) | __float_as_int(x);
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char *)p;
 }
 
-// The filter for NS spheres x NK rays, written stage by stage so that consecutive
-// instructions belong to different (sphere, ray) pairs: a wave's next instruction then never
-// waits for the previous one (a dependent FMA cannot issue back to back).
-//   op[u]   o - p of sphere u          c2[u]  its filter constant
-//   dn[k]   -d of ray k                out[u] AND over the rays of (bits(v) | bits(x'))
-template <int NS, int NK>
-__device__ __forceinline__ void filter_block(const f3 (&dn)[NK], const float fm, const f3 (&op)[NS],
-                                             const float (&c2)[NS], int (&out)[NS])
-{
-    float x[NS][NK];
-#pragma unroll
-    for (int u = 0; u < NS; u++)
-#pragma unroll
-        for (int k = 0; k < NK; k++) x[u][k] = __builtin_fmaf(dn[k].x, op[u].x, fm);
-#pragma unroll
-    for (int u = 0; u < NS; u++)
-#pragma unroll
-        for (int k = 0; k < NK; k++) x[u][k] = __builtin_fmaf(dn[k].y, op[u].y, x[u][k]);
-#pragma unroll
-    for (int u = 0; u < NS; u++)
-#pragma unroll
-        for (int k = 0; k < NK; k++) x[u][k] = __builtin_fmaf(dn[k].z, op[u].z, x[u][k]);
-    int w[NS][NK];
-#pragma unroll
-    for (int u = 0; u < NS; u++)
-#pragma unroll
-        for (int k = 0; k < NK; k++)
-            w[u][k] = __float_as_int(__builtin_fmaf(x[u][k], x[u][k], -c2[u])) | __float_as_int(x[u][k]);
-#pragma unroll
-    for (int u = 0; u < NS; u++) {
-        int a = w[u][0];
-#pragma unroll
-        for (int k = 1; k < NK; k++) a &= w[u][k];
-        out[u] = a;
-    }
-}
+__device__ __forceinline__ f4raw ray_operand(f3 d) { return f4raw{0.0f, d.x, d.y, d.z}; }
 
 // GetRayDirection's per-pixel part, MyApplication.cs:438-449.
 __device__ __forceinline__ f3 primary_direction(const DevCamera &cam, int px, int py)
@@ -323,7 +320,8 @@ __device__ __forceinline__ f3 primary_direction(const DevCamera &cam, int px, in
 
 __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevFrame f, int32_t *pixels)
 {
-    __shared__ float4 lds[SPH_CHUNK + SPH_BATCH];
+    __shared__ float4 lds[SPH_LDS_ENTRIES];
+    __shared__ int blk[12];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rows = cam.row_end - cam.row_begin;
     const int tiles_x = (cam.width + 31) >> 5, tiles_y = (rows + 31) >> 5;
@@ -336,13 +334,14 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
         stage_spheres(lds, s.sph_cam, 0, nsp);
         __syncthreads();
     }
+    int exact_batches = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = tile / tiles_x;
         const int x0 = tx * 32 + (wave & 1) * 16 + (lane & 7) * 2;
         const int y0 = cam.row_begin + ty * 32 + (wave >> 1) * 16 + (lane >> 3) * 2;
         bool inside[PRIM_PX];
         int px[PRIM_PX], py[PRIM_PX];
-        f3 d[PRIM_PX], dn[PRIM_PX];
+        f3 d[PRIM_PX];
         float a[PRIM_PX], best_t[PRIM_PX];
         int best_i[PRIM_PX];
 #pragma unroll
@@ -353,7 +352,6 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
             px[k] = x < cam.width ? x : cam.width - 1;
             py[k] = y < cam.row_end ? y : cam.row_end - 1;
             d[k] = primary_direction(cam, px[k], py[k]);
-            dn[k] = mk3(-d[k].x, -d[k].y, -d[k].z);
             a[k] = dot3(d[k], d[k]);
             best_t[k] = RT_FLT_MAX;   // strict `<` within the class keeps the first of equals
             best_i[k] = -1;
@@ -365,56 +363,46 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
                 stage_spheres(lds, s.sph_cam, base, cnt);
                 __syncthreads();
             }
-            // One batch: filter SPH_BATCH spheres in straight-line code, then one branch to
-            // the exact evaluation for the spheres some lane could hit.
-            auto batch = [&](const float4 (&sp)[SPH_BATCH], const int first) {
-                int pass[SPH_BATCH], all = -1;
-                f3 op[SPH_BATCH];
-                float c2[SPH_BATCH];
+            const f4raw r0 = ray_operand(d[0]), r1 = ray_operand(d[1]), r2 = ray_operand(d[2]),
+                        r3 = ray_operand(d[3]);
+            int i = 0;
+            unsigned addr = lds_offset(lds);
+            while (i < cnt) {
+                f4raw sp[SPH_BATCH];
+                int pass[SPH_BATCH];
+                asm volatile(FA_PRIMARY4_ASM
+                             : [i] "+s"(i), [addr] "+v"(addr), FA_SP0(sp[0]), FA_SP1(sp[1]), FA_SP2(sp[2]),
+                               FA_SP3(sp[3]), FA_ACC0(pass[0]), FA_ACC1(pass[1]), FA_ACC2(pass[2]), FA_ACC3(pass[3])
+                             : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), FA_FM(fm), [cnt] "s"(cnt)
+                             : FA_PRIMARY4_CLOBBERS);
+                if (i >= cnt) break;
+                exact_batches++;
+                // Exact evaluation of the batch the loop stopped at: objects.cs:112-121 literally;
+                // c for the camera origin as setup_camera stored it.
 #pragma unroll
                 for (int u = 0; u < SPH_BATCH; u++) {
-                    op[u] = xyz(sp[u]);
-                    c2[u] = sp[u].w;
-                }
-                filter_block<SPH_BATCH, PRIM_PX>(dn, fm, op, c2, pass);
+                    if (pass[u] >= 0) {
+                        const f3 op = mk3(sp[u].x, sp[u].y, sp[u].z);
+                        const float c = cload(s.sph_cam_c, base + i + u);
 #pragma unroll
-                for (int u = 0; u < SPH_BATCH; u++) all &= pass[u];
-                if (all >= 0) {
-#pragma unroll
-                    for (int u = 0; u < SPH_BATCH; u++) {
-                        if (pass[u] >= 0) {
-                            // objects.cs:112-121 literally; c for the camera origin as setup_camera
-                            // stores it next to the filter constant.
-                            const float c = cload(s.sph_cam_c, first + u);
-#pragma unroll
-                            for (int k = 0; k < PRIM_PX; k++) {
-                                const float xx = dot3(d[k], xyz(sp[u]));
-                                float t;
-                                if (sphere_maybe(xx, a[k] * c) && sphere_root(xx, c, a[k], t) && t < best_t[k] &&
-                                    t > RT_EPS) {
-                                    best_t[k] = t;
-                                    best_i[k] = first + u;
-                                }
+                        for (int k = 0; k < PRIM_PX; k++) {
+                            const float xx = dot3(d[k], op);
+                            float t;
+                            if (sphere_maybe(xx, a[k] * c) && sphere_root(xx, c, a[k], t) && t < best_t[k] &&
+                                t > RT_EPS) {
+                                best_t[k] = t;
+                                best_i[k] = base + i + u;
                             }
                         }
                     }
                 }
-            };
-            // Two register sets in ping-pong: the LDS reads of one batch are in flight while
-            // the other is computed (cnt is a multiple of 2*SPH_BATCH; the array has a batch
-            // of slack behind it for the last read-ahead).
-            float4 s0[SPH_BATCH], s1[SPH_BATCH];
-#pragma unroll
-            for (int u = 0; u < SPH_BATCH; u++) s0[u] = lds[u];
-            for (int i = 0; i < cnt; i += 2 * SPH_BATCH) {
-#pragma unroll
-                for (int u = 0; u < SPH_BATCH; u++) s1[u] = lds[i + SPH_BATCH + u];
-                batch(s0, base + i);
-#pragma unroll
-                for (int u = 0; u < SPH_BATCH; u++) s0[u] = lds[i + 2 * SPH_BATCH + u];
-                batch(s1, base + i + SPH_BATCH);
+                i += SPH_BATCH;
+                addr += SPH_BATCH * 16;
             }
         }
+        bool rec_valid[PRIM_PX];
+        int rec_prim[PRIM_PX], rec_parent[PRIM_PX];
+        f3 rec_hit[PRIM_PX];
 #pragma unroll
         for (int k = 0; k < PRIM_PX; k++) {
             Closest c;
@@ -435,11 +423,15 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
             }
             const bool hit = inside[k] && c.prim != INT_MAX;
             const int pix = (py[k] - cam.row_begin) * cam.width + px[k];
-            const f3 hp = add3(o, scale3(d[k], c.t));
-            push_record(f, s, 0, hit, hit ? c.prim : 0, hp, d[k], pix);
+            rec_valid[k] = hit;
+            rec_prim[k] = hit ? c.prim : 0;
+            rec_parent[k] = pix;
+            rec_hit[k] = add3(o, scale3(d[k], c.t));
             if (inside[k] && !hit) pixels[pix] = 0;  // MyApplication.cs:423
         }
+        push_records<PRIM_PX>(f, s, 0, blk, rec_valid, rec_prim, rec_hit, d, rec_parent);
     }
+    if (lane == 0 && exact_batches) atomicAdd(&f.counters->exact_batches, (unsigned long long)exact_batches);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -462,17 +454,18 @@ struct Rays {
 
 template <int LC, bool SEC>
 __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, const bool single, const f3 o,
-                                         Rays<LC, SEC> &r)
+                                         Rays<LC, SEC> &r, int &exact_batches)
 {
     constexpr int NR = LC + (SEC ? 1 : 0);
-    f3 dn[NR > 0 ? NR : 1];
+    static_assert(NR >= 1 && NR <= 5, "one filter loop per ray count 1..5");
+    // Ray operands of the filter loop: light rays first, the reflection ray last.
+    f4raw rq[5];
 #pragma unroll
-    for (int l = 0; l < LC; l++) dn[l] = mk3(-r.sh_d[l].x, -r.sh_d[l].y, -r.sh_d[l].z);
-    if (SEC) dn[LC] = mk3(-r.sec_d.x, -r.sec_d.y, -r.sec_d.z);
+    for (int l = 0; l < LC; l++) rq[l] = ray_operand(r.sh_d[l]);
+    if (SEC) rq[LC] = ray_operand(r.sec_d);
+    const f4raw oq = f4raw{o.x, o.y, o.z, 0.0f};
     const float fm = FILTER_FM_SCALE * (((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) + s.sph_l1max);
-    // Kept in a VGPR: as an SGPR or literal operand it would halve the FMA's issue rate.
-    float k1 = FILTER_K1;
-    asm volatile("" : "+v"(k1));
+    const float k1 = FILTER_K1;
 
     float best_t = RT_FLT_MAX;
     int best_i = -1;
@@ -484,61 +477,53 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, const b
             stage_spheres(lds, s.sph, base, cnt);
             __syncthreads();
         }
-        auto batch = [&](const float4 (&sp)[SPH_BATCH], const int first) {
-            int pass[SPH_BATCH], all = -1;
-            f3 op[SPH_BATCH];
-            float q[SPH_BATCH], c2[SPH_BATCH];
+        int i = 0;
+        unsigned addr = lds_offset(lds);
+        while (i < cnt) {
+            f4raw sp[SPH_BATCH];
+            int pass[SPH_BATCH];
+#define FA_RUN(NAME, ...)                                                                                   \
+    asm volatile(NAME##_ASM                                                                                 \
+                 : [i] "+s"(i), [addr] "+v"(addr), FA_SP0(sp[0]), FA_SP1(sp[1]), FA_SP2(sp[2]), FA_SP3(sp[3]), \
+                   FA_ACC0(pass[0]), FA_ACC1(pass[1]), FA_ACC2(pass[2]), FA_ACC3(pass[3])                   \
+                 : __VA_ARGS__, FA_O(oq), FA_K1(k1), FA_FM(fm), [cnt] "s"(cnt)                              \
+                 : NAME##_CLOBBERS)
+            if constexpr (NR == 1) FA_RUN(FA_TRACE1, FA_DN0(rq[0]));
+            if constexpr (NR == 2) FA_RUN(FA_TRACE2, FA_DN0(rq[0]), FA_DN1(rq[1]));
+            if constexpr (NR == 3) FA_RUN(FA_TRACE3, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]));
+            if constexpr (NR == 4) FA_RUN(FA_TRACE4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]));
+            if constexpr (NR == 5)
+                FA_RUN(FA_TRACE5, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_DN4(rq[4]));
+#undef FA_RUN
+            if (i >= cnt) break;
+            exact_batches++;
+            // Exact evaluation of the batch the loop stopped at.
 #pragma unroll
-            for (int u = 0; u < SPH_BATCH; u++) op[u] = sub3(o, xyz(sp[u]));
-#pragma unroll
-            for (int u = 0; u < SPH_BATCH; u++) q[u] = op[u].x * op[u].x;
-#pragma unroll
-            for (int u = 0; u < SPH_BATCH; u++) q[u] = __builtin_fmaf(op[u].y, op[u].y, q[u]);
-#pragma unroll
-            for (int u = 0; u < SPH_BATCH; u++) q[u] = __builtin_fmaf(op[u].z, op[u].z, q[u]);
-#pragma unroll
-            for (int u = 0; u < SPH_BATCH; u++) c2[u] = __builtin_fmaf(q[u], k1, -sp[u].w);
-            filter_block<SPH_BATCH, (NR > 0 ? NR : 1)>(dn, fm, op, c2, pass);
-#pragma unroll
-            for (int u = 0; u < SPH_BATCH; u++) all &= pass[u];
-            if (all >= 0) {
-#pragma unroll
-                for (int u = 0; u < SPH_BATCH; u++) {
-                    if (pass[u] >= 0) {
-                        // Sphere.Intersect objects.cs:112-121, literally.
-                        const f3 op = sub3(o, xyz(sp[u]));
-                        const float c = dot3(op, op) - sp[u].w;
-                        float t;
-                        if (SEC) {
-                            const float x = dot3(r.sec_d, op);
-                            if (sphere_maybe(x, r.sec_a * c) && sphere_root(x, c, r.sec_a, t) && t < best_t &&
-                                t > RT_EPS) {
-                                best_t = t;
-                                best_i = first + u;
-                            }
+            for (int u = 0; u < SPH_BATCH; u++) {
+                if (pass[u] >= 0) {
+                    // Sphere.Intersect objects.cs:112-121, literally.
+                    const f3 op = sub3(o, mk3(sp[u].x, sp[u].y, sp[u].z));
+                    const float c = dot3(op, op) - sp[u].w;
+                    float t;
+                    if (SEC) {
+                        const float x = dot3(r.sec_d, op);
+                        if (sphere_maybe(x, r.sec_a * c) && sphere_root(x, c, r.sec_a, t) && t < best_t &&
+                            t > RT_EPS) {
+                            best_t = t;
+                            best_i = base + i + u;
                         }
+                    }
 #pragma unroll
-                        for (int l = 0; l < LC; l++) {
-                            const float x = dot3(r.sh_d[l], op);
-                            if (sphere_maybe(x, r.sh_a[l] * c) && sphere_root(x, c, r.sh_a[l], t) && t > RT_EPS &&
-                                t < r.sh_dist[l])
-                                r.sh_first[l] = min(r.sh_first[l], cload(s.sph_orig, first + u));
-                        }
+                    for (int l = 0; l < LC; l++) {
+                        const float x = dot3(r.sh_d[l], op);
+                        if (sphere_maybe(x, r.sh_a[l] * c) && sphere_root(x, c, r.sh_a[l], t) && t > RT_EPS &&
+                            t < r.sh_dist[l])
+                            r.sh_first[l] = min(r.sh_first[l], cload(s.sph_orig, base + i + u));
                     }
                 }
             }
-        };
-        // Ping-pong register sets, as in the primary kernel.
-        float4 s0[SPH_BATCH], s1[SPH_BATCH];
-#pragma unroll
-        for (int u = 0; u < SPH_BATCH; u++) s0[u] = lds[u];
-        for (int i = 0; i < cnt; i += 2 * SPH_BATCH) {
-#pragma unroll
-            for (int u = 0; u < SPH_BATCH; u++) s1[u] = lds[i + SPH_BATCH + u];
-            batch(s0, base + i);
-#pragma unroll
-            for (int u = 0; u < SPH_BATCH; u++) s0[u] = lds[i + 2 * SPH_BATCH + u];
-            batch(s1, base + i + SPH_BATCH);
+            i += SPH_BATCH;
+            addr += SPH_BATCH * 16;
         }
     }
     if (SEC) {
@@ -589,6 +574,7 @@ __device__ __forceinline__ f3 record_normal(const DevScene &s, int prim, int typ
 
 struct TestCount {
     int sph, pl, tri;
+    int exact;   // batches this wave sent to the exact code (wave-uniform)
 };
 
 // One chunk of LC lights (plus the reflection ray when SEC) for one record.
@@ -614,7 +600,7 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, cons
         r.sec.t = RT_FLT_MAX;
         r.sec.prim = INT_MAX;
     }
-    traverse<LC, SEC>(s, lds, single, hit, r);
+    traverse<LC, SEC>(s, lds, single, hit, r, tc.exact);
 #pragma unroll
     for (int l = 0; l < LC; l++) {
         const bool occluded = r.sh_first[l] != INT_MAX;
@@ -641,7 +627,8 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, cons
 template <bool SEC, int LCMAX>
 __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level)
 {
-    __shared__ float4 lds[SPH_CHUNK + SPH_BATCH];
+    __shared__ float4 lds[SPH_LDS_ENTRIES];
+    __shared__ int blk[12];
     const int n = SEC ? f.cnt[2 * level] : f.cnt[2 * level + 1];
     const int ntiles = (n + 255) >> 8;
     const bool single = s.ns_padded <= SPH_CHUNK;
@@ -649,7 +636,7 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
         stage_spheres(lds, s.sph, 0, s.ns_padded);
         __syncthreads();
     }
-    TestCount tc = {0, 0, 0};
+    TestCount tc = {0, 0, 0, 0};
     // Workgroup-uniform trip count: the sphere chunks are staged between barriers.
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int i = tile * 256 + threadIdx.x;
@@ -664,7 +651,7 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
 
         Closest sec = {RT_FLT_MAX, INT_MAX};
         f3 sec_dir = mk3(0.0f, 0.0f, 0.0f);
-        TestCount ltc = {0, 0, 0};
+        TestCount ltc = {0, 0, 0, 0};
         uint32_t word = 0;
         int l0 = 0;
         bool first = true;
@@ -698,11 +685,15 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
             tc.pl += ltc.pl;
             tc.tri += ltc.tri;
         }
+        tc.exact += ltc.exact;
         if (SEC) {
             const bool child = active && sec.prim != INT_MAX;
             const f3 hit2 = add3(hit, scale3(sec_dir, sec.t));   // objects.cs:123,166,263
             if (active) f.refl[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            push_record(f, s, level + 1, child, child ? sec.prim : 0, hit2, sec_dir, slot);
+            const bool rv[1] = {child};
+            const int rp[1] = {child ? sec.prim : 0}, rparent[1] = {slot};
+            const f3 rh[1] = {hit2}, rd[1] = {sec_dir};
+            push_records<1>(f, s, level + 1, blk, rv, rp, rh, rd, rparent);
         }
     }
     const int ws = wave_sum(tc.sph), wp = wave_sum(tc.pl), wt = wave_sum(tc.tri);
@@ -711,6 +702,7 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
         atomicAdd(&f.counters->plane_tests, (unsigned long long)wp);
         atomicAdd(&f.counters->triangle_tests, (unsigned long long)wt);
     }
+    if ((threadIdx.x & 63) == 0 && tc.exact) atomicAdd(&f.counters->exact_batches, (unsigned long long)tc.exact);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_the_header_layout():
     assert ctypes.sizeof(abi.rt_camera) == 40
     assert ctypes.sizeof(abi.rt_scene) == 8 + 16 * 8
-    assert ctypes.sizeof(abi.rt_stats) == 7 * 8 + 6 * 8 + 8
+    assert ctypes.sizeof(abi.rt_stats) == 8 * 8 + 6 * 8 + 8
 
 
 def test_no_device_is_an_error_not_a_crash():

@@ -1,0 +1,83 @@
+// filter_loop_bench.hip — runs the generated primary filter loop (filter_asm.inc) alone on
+// never-passing data and reports cycles per VALU instruction, per occupancy.
+// Build: hipcc --offload-arch=gfx950 -O3 -I raytracer_amd/csrc tools/filter_loop_bench.hip -o tools/filter_loop_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+#include "filter_asm.inc"
+typedef float f4raw __attribute__((ext_vector_type(4)));
+#define CH 1024
+
+template <int PAD>
+__global__ void __launch_bounds__(256) k(const float4 *sph, int reps, float *out)
+{
+    __shared__ float4 lds[CH + FA_LDS_SLACK];
+    __shared__ float pad[PAD > 0 ? PAD : 1];   // extra LDS to cap the workgroups per CU
+    for (int i = threadIdx.x; i < CH + FA_LDS_SLACK; i += 256) lds[i] = sph[i];
+    if (PAD > 0) pad[threadIdx.x % PAD] = 0.f;
+    __syncthreads();
+    const float t = 1e-3f * threadIdx.x;
+    const f4raw r0 = {0.f, 0.6f + t, 0.0f, 0.8f}, r1 = {0.f, 0.6f, t, 0.8f}, r2 = {0.f, 0.0f, 0.6f + t, 0.8f},
+                r3 = {0.f, t, 0.6f, 0.8f};
+    const float fm = 1e-5f;
+    int hits = 0;
+    for (int r = 0; r < reps; r++) {
+        int i = 0;
+        const int cnt = CH;
+        unsigned addr = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char *)lds;
+        while (i < cnt) {
+            f4raw sp[4];
+            int pass[4];
+            asm volatile(FA_PRIMARY4_ASM
+                         : [i] "+s"(i), [addr] "+v"(addr), FA_SP0(sp[0]), FA_SP1(sp[1]), FA_SP2(sp[2]), FA_SP3(sp[3]),
+                           FA_ACC0(pass[0]), FA_ACC1(pass[1]), FA_ACC2(pass[2]), FA_ACC3(pass[3])
+                         : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), FA_FM(fm), [cnt] "s"(cnt)
+                         : FA_PRIMARY4_CLOBBERS);
+            if (i >= cnt) break;
+            hits += (pass[0] >= 0) + (pass[1] >= 0) + (pass[2] >= 0) + (pass[3] >= 0) + (sp[0].x > 0);
+            i += 4;
+            addr += 64;
+        }
+    }
+    if (PAD > 0) hits += (int)pad[0];
+    out[blockIdx.x * 256 + threadIdx.x] = (float)hits;
+}
+
+template <int PAD>
+void run(const char *what, int blocks, const float4 *dsph, float *dout)
+{
+    const int reps = 20;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<PAD>, dim3(blocks), dim3(256), 0, 0, dsph, reps, dout);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(k<PAD>, dim3(blocks), dim3(256), 0, 0, dsph, reps, dout);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    // 169 VALU per trip of 8 spheres (see filter_asm.inc)
+    const double instr_per_wave = (double)reps * (CH / 8) * 169.0;
+    const double waves_per_simd = blocks * 4.0 / 1024.0;
+    printf("%-34s blocks %5d  %8.3f ms  %.2f cycles per VALU instr per SIMD @2.4GHz\n", what, blocks, ms,
+           ms * 1e-3 * 2.4e9 / (instr_per_wave * waves_per_simd));
+}
+
+int main()
+{
+    std::vector<float4> sph(CH + FA_LDS_SLACK);
+    for (size_t i = 0; i < sph.size(); i++) sph[i] = make_float4(1.f + 0.001f * i, -2.f, 3.f, -INFINITY);
+    float4 *dsph;
+    float *dout;
+    (void)hipMalloc(&dsph, sph.size() * sizeof(float4));
+    (void)hipMalloc(&dout, 8192 * 256 * sizeof(float));
+    (void)hipMemcpy(dsph, sph.data(), sph.size() * sizeof(float4), hipMemcpyHostToDevice);
+    run<0>("1 wave/SIMD  (256 blocks)", 256, dsph, dout);
+    run<0>("2 waves/SIMD (512 blocks)", 512, dsph, dout);
+    run<0>("4 waves/SIMD (1024 blocks)", 1024, dsph, dout);
+    run<0>("8 waves/SIMD requested (2048)", 2048, dsph, dout);
+    return 0;
+}
