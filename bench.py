@@ -150,7 +150,7 @@ def main() -> None:
                 "spheres": ns, "planes": npl, "lights": flat.num_lights,
                 "partition": f"{world} contiguous row block(s), RCCL gather to rank 0",
                 "rays_per_frame": int(rays),
-                "exact_batches_rank0": int(st["exact_batches"]),
+                "exact_candidates_rank0": int(st["exact_candidates"]),
             },
             "roofline": {
                 "bound": "valu-fp32", "kernel": "k_trace<true>+k_trace<false>, levels 0..4",

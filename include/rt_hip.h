@@ -121,8 +121,8 @@ typedef struct rt_stats {
     uint64_t sphere_tests;
     uint64_t plane_tests;
     uint64_t triangle_tests;
-    uint64_t exact_batches;   /* 4-sphere batches (per wave) that left the conservative
-                                 sphere filter for the exact Intersect code: a cost figure */
+    uint64_t exact_candidates; /* (ray origin, sphere) pairs the conservative sphere filter
+                                  passed on to the exact Intersect code: a cost figure      */
     double   kernel_ms;
     double   primary_ms;
     double   trace_ms;

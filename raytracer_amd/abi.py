@@ -72,7 +72,7 @@ class rt_stats(C.Structure):
         ("sphere_tests", C.c_uint64),
         ("plane_tests", C.c_uint64),
         ("triangle_tests", C.c_uint64),
-        ("exact_batches", C.c_uint64),
+        ("exact_candidates", C.c_uint64),
         ("kernel_ms", C.c_double),
         ("primary_ms", C.c_double),
         ("trace_ms", C.c_double),

@@ -24,6 +24,9 @@ struct DeviceState {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {};  // begin, after primary, after trace, after shade, after gather copy
+    hipStream_t side = nullptr;             // second stream: plain-surface traces run beside
+    hipEvent_t fork[RT_MAX_DEPTH + 2] = {}; // the reflection chain (see enqueue_rows)
+    hipEvent_t join = nullptr;
     int num_cus = 256;
 
     // scene
@@ -360,7 +363,22 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     rtk_setup_camera(d.scene, dc, d.sph_cam, d.sph_cam_c, stream);
     rtk_primary(d.scene, dc, f, dev_pixels, blocks, stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[1], stream));
-    for (int k = 0; k <= max_depth; k++) rtk_trace_level(d.scene, f, k, blocks, stream);
+    // Two dependency chains: level k+1's records exist once level k's reflecting records
+    // (queue A) are traced, so A0 -> A1 -> ... is serial and its deep levels are tiny
+    // launches that cannot fill the chip; the plain records of a level (queue B, most of
+    // the work, no successors) only need that level's records.  B_k therefore runs on a
+    // second stream beside A_k, A_{k+1}, ... and the small launches hide under the big ones.
+    HIP_TRY(ctx, hipEventRecord(d.fork[0], stream));
+    for (int k = 0; k <= max_depth; k++) {
+        HIP_TRY(ctx, hipStreamWaitEvent(d.side, d.fork[k], 0));
+        rtk_trace(d.scene, f, k, false, blocks, d.side);
+        if (k < max_depth) {
+            rtk_trace(d.scene, f, k, true, blocks, stream);
+            HIP_TRY(ctx, hipEventRecord(d.fork[k + 1], stream));
+        }
+    }
+    HIP_TRY(ctx, hipEventRecord(d.join, d.side));
+    HIP_TRY(ctx, hipStreamWaitEvent(stream, d.join, 0));
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[2], stream));
     for (int k = max_depth; k >= 0; k--) rtk_shade_level(d.scene, f, k, dev_pixels, blocks, stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[3], stream));
@@ -411,6 +429,10 @@ int rt_create(rt_ctx **out, const int *device_ids, int n_devices)
         }
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipEventCreate(&d.ev[k]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking);
+        for (int k = 0; k < RT_MAX_DEPTH + 2 && e == hipSuccess; k++)
+            e = hipEventCreateWithFlags(&d.fork[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d.join, hipEventDisableTiming);
         if (e != hipSuccess) {
             int rc = fail(nullptr, RT_ERR_HIP, "device %d setup failed: %s", d.device, hipGetErrorString(e));
             rt_destroy(ctx);
@@ -445,6 +467,10 @@ void rt_destroy(rt_ctx *ctx)
         free_frame(d);
         for (int k = 0; k < 5; k++)
             if (d.ev[k]) (void)hipEventDestroy(d.ev[k]);
+        for (int k = 0; k < RT_MAX_DEPTH + 2; k++)
+            if (d.fork[k]) (void)hipEventDestroy(d.fork[k]);
+        if (d.join) (void)hipEventDestroy(d.join);
+        if (d.side) (void)hipStreamSynchronize(d.side), (void)hipStreamDestroy(d.side);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
     if (ctx->staging) (void)hipHostFree(ctx->staging);
@@ -652,13 +678,14 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out)
         out->sphere_tests += c.sphere_tests + P * (uint64_t)d.scene.ns;
         out->plane_tests += c.plane_tests + P * (uint64_t)d.scene.np;
         out->triangle_tests += c.triangle_tests + P * (uint64_t)d.scene.nt;
-        out->exact_batches += c.exact_batches;
+        out->exact_candidates += c.exact_candidates;
         if (d.timed) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, d.ev[0], d.ev[3]) == hipSuccess) kernel_ms = std::max(kernel_ms, (double)ms);
             if (hipEventElapsedTime(&ms, d.ev[0], d.ev[1]) == hipSuccess) primary_ms = std::max(primary_ms, (double)ms);
             if (hipEventElapsedTime(&ms, d.ev[1], d.ev[2]) == hipSuccess) trace_ms = std::max(trace_ms, (double)ms);
             if (hipEventElapsedTime(&ms, d.ev[2], d.ev[3]) == hipSuccess) shade_ms = std::max(shade_ms, (double)ms);
+            (void)hipGetLastError();  // a failed query must not linger as the process's last error
         }
     }
     out->kernel_ms = kernel_ms;

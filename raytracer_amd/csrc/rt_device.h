@@ -76,7 +76,7 @@ struct DevCounters {
     unsigned long long sphere_tests;
     unsigned long long plane_tests;
     unsigned long long triangle_tests;
-    unsigned long long exact_batches;   // wave-level: 4-sphere batches sent to the exact code
+    unsigned long long exact_candidates;   // (ray origin, sphere) pairs evaluated exactly
 };
 
 // Hit records: the bounce stack of every pixel, kept in HBM.  Level k of the frame
@@ -107,7 +107,8 @@ void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, 
                       hipStream_t stream);
 void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels,
                  int grid_blocks, hipStream_t stream);
-void rtk_trace_level(const DevScene &s, const DevFrame &f, int level, int grid_blocks,
-                     hipStream_t stream);
+// reflecting: the level's records that need a reflection trace (queue A) or the others (B).
+void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting, int grid_blocks,
+               hipStream_t stream);
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
                      int grid_blocks, hipStream_t stream);

@@ -272,15 +272,19 @@ __global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam,
 // The filter loops themselves are gfx950 assembly with a fixed, VGPR-bank-conflict-free
 // register plan (filter_asm.inc, generated by tools/gen_filter_asm.py): hipcc's register
 // allocation ignores banks, and a three-source instruction with two sources in one bank
-// issues at half rate.  A loop walks the spheres staged in LDS, four per batch, and returns
-// at the first batch in which some lane's ray could hit a sphere; the exact evaluation of
-// that batch happens here in C++, then the loop is re-entered behind it.
+// issues at half rate.  A loop walks the spheres staged in LDS, four per batch; lanes whose
+// rays could hit a sphere of the batch queue its index in LDS and the loop goes on.  The
+// exact evaluation then runs here in C++ over each lane's (short) queue, in index order.
 
 // Spheres staged per workgroup: SPH_CHUNK entries of {cx, cy, cz, r*r} (or, for the primary
 // kernel, {ox-cx, oy-cy, oz-cz, -c''}) plus FA_LDS_SLACK never-pass entries for the loops'
 // read-ahead.
 #define SPH_CHUNK 1024
 #define SPH_LDS_ENTRIES (SPH_CHUNK + FA_LDS_SLACK)
+// Candidate queues: QUEUE_SLOTS sphere indices per thread, slot-major (slot s of thread t at
+// int index 256*s + t).  A loop returns early when a queue could not take another batch.
+#define QUEUE_SLOTS 16
+#define QUEUE_INTS (QUEUE_SLOTS * 256)
 
 __device__ __forceinline__ void stage_spheres(float4 *lds, const float4 *src, int base, int count)
 {
@@ -321,6 +325,7 @@ __device__ __forceinline__ f3 primary_direction(const DevCamera &cam, int px, in
 __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevFrame f, int32_t *pixels)
 {
     __shared__ float4 lds[SPH_LDS_ENTRIES];
+    __shared__ int cand[QUEUE_INTS];
     __shared__ int blk[12];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rows = cam.row_end - cam.row_begin;
@@ -334,7 +339,7 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
         stage_spheres(lds, s.sph_cam, 0, nsp);
         __syncthreads();
     }
-    int exact_batches = 0;
+    int candidates = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = tile / tiles_x;
         const int x0 = tx * 32 + (wave & 1) * 16 + (lane & 7) * 2;
@@ -365,25 +370,28 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
             }
             const f4raw r0 = ray_operand(d[0]), r1 = ray_operand(d[1]), r2 = ray_operand(d[2]),
                         r3 = ray_operand(d[3]);
+            const unsigned q0 = lds_offset(cand) + 4u * threadIdx.x;
+            const unsigned qlim = lds_offset(cand) + (QUEUE_SLOTS - FA_TRIP) * FA_QUEUE_STRIDE + 4u * 255u;
+            unsigned qaddr = q0, addr = lds_offset(lds);
             int i = 0;
-            unsigned addr = lds_offset(lds);
-            while (i < cnt) {
-                f4raw sp[SPH_BATCH];
-                int pass[SPH_BATCH];
-                asm volatile(FA_PRIMARY4_ASM
-                             : [i] "+s"(i), [addr] "+v"(addr), FA_SP0(sp[0]), FA_SP1(sp[1]), FA_SP2(sp[2]),
-                               FA_SP3(sp[3]), FA_ACC0(pass[0]), FA_ACC1(pass[1]), FA_ACC2(pass[2]), FA_ACC3(pass[3])
-                             : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), FA_FM(fm), [cnt] "s"(cnt)
-                             : FA_PRIMARY4_CLOBBERS);
-                if (i >= cnt) break;
-                exact_batches++;
-                // Exact evaluation of the batch the loop stopped at: objects.cs:112-121 literally;
-                // c for the camera origin as setup_camera stored it.
-#pragma unroll
-                for (int u = 0; u < SPH_BATCH; u++) {
-                    if (pass[u] >= 0) {
-                        const f3 op = mk3(sp[u].x, sp[u].y, sp[u].z);
-                        const float c = cload(s.sph_cam_c, base + i + u);
+            while (true) {
+                if (i < cnt)
+                    asm volatile(FA_PRIMARY4_ASM
+                                 : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
+                                 : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), FA_FM(fm), [cnt] "s"(cnt),
+                                   [qlim] "s"(qlim)
+                                 : FA_PRIMARY4_CLOBBERS);
+                // Exact evaluation of the queued spheres: objects.cs:112-121 literally; c for the
+                // camera origin as setup_camera stored it.  Queue order = index order, so the
+                // strict `<` keeps the first of equal distances.
+                const int nq = (int)((qaddr - q0) / FA_QUEUE_STRIDE);
+                candidates += nq;
+                for (int j = 0; __ballot(j < nq) != 0ull; j++) {
+                    if (j < nq) {
+                        const int li = cand[j * 256 + threadIdx.x];
+                        const float4 sp = lds[li];
+                        const f3 op = xyz(sp);
+                        const float c = s.sph_cam_c[base + li];
 #pragma unroll
                         for (int k = 0; k < PRIM_PX; k++) {
                             const float xx = dot3(d[k], op);
@@ -391,13 +399,13 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
                             if (sphere_maybe(xx, a[k] * c) && sphere_root(xx, c, a[k], t) && t < best_t[k] &&
                                 t > RT_EPS) {
                                 best_t[k] = t;
-                                best_i[k] = base + i + u;
+                                best_i[k] = base + li;
                             }
                         }
                     }
                 }
-                i += SPH_BATCH;
-                addr += SPH_BATCH * 16;
+                qaddr = q0;
+                if (i >= cnt) break;
             }
         }
         bool rec_valid[PRIM_PX];
@@ -431,7 +439,8 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
         }
         push_records<PRIM_PX>(f, s, 0, blk, rec_valid, rec_prim, rec_hit, d, rec_parent);
     }
-    if (lane == 0 && exact_batches) atomicAdd(&f.counters->exact_batches, (unsigned long long)exact_batches);
+    candidates = wave_sum(candidates);
+    if (lane == 0 && candidates) atomicAdd(&f.counters->exact_candidates, (unsigned long long)candidates);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -453,8 +462,8 @@ struct Rays {
 };
 
 template <int LC, bool SEC>
-__device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, const bool single, const f3 o,
-                                         Rays<LC, SEC> &r, int &exact_batches)
+__device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, int *cand, const bool single,
+                                         const f3 o, Rays<LC, SEC> &r, int &candidates)
 {
     constexpr int NR = LC + (SEC ? 1 : 0);
     static_assert(NR >= 1 && NR <= 5, "one filter loop per ray count 1..5");
@@ -477,40 +486,43 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, const b
             stage_spheres(lds, s.sph, base, cnt);
             __syncthreads();
         }
+        const unsigned q0 = lds_offset(cand) + 4u * threadIdx.x;
+        const unsigned qlim = lds_offset(cand) + (QUEUE_SLOTS - FA_TRIP) * FA_QUEUE_STRIDE + 4u * 255u;
+        unsigned qaddr = q0, addr = lds_offset(lds);
         int i = 0;
-        unsigned addr = lds_offset(lds);
-        while (i < cnt) {
-            f4raw sp[SPH_BATCH];
-            int pass[SPH_BATCH];
-#define FA_RUN(NAME, ...)                                                                                   \
-    asm volatile(NAME##_ASM                                                                                 \
-                 : [i] "+s"(i), [addr] "+v"(addr), FA_SP0(sp[0]), FA_SP1(sp[1]), FA_SP2(sp[2]), FA_SP3(sp[3]), \
-                   FA_ACC0(pass[0]), FA_ACC1(pass[1]), FA_ACC2(pass[2]), FA_ACC3(pass[3])                   \
-                 : __VA_ARGS__, FA_O(oq), FA_K1(k1), FA_FM(fm), [cnt] "s"(cnt)                              \
+        while (true) {
+#define FA_RUN(NAME, ...)                                                                 \
+    asm volatile(NAME##_ASM                                                               \
+                 : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)                    \
+                 : __VA_ARGS__, FA_O(oq), FA_K1(k1), FA_FM(fm), [cnt] "s"(cnt), [qlim] "s"(qlim) \
                  : NAME##_CLOBBERS)
-            if constexpr (NR == 1) FA_RUN(FA_TRACE1, FA_DN0(rq[0]));
-            if constexpr (NR == 2) FA_RUN(FA_TRACE2, FA_DN0(rq[0]), FA_DN1(rq[1]));
-            if constexpr (NR == 3) FA_RUN(FA_TRACE3, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]));
-            if constexpr (NR == 4) FA_RUN(FA_TRACE4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]));
-            if constexpr (NR == 5)
-                FA_RUN(FA_TRACE5, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_DN4(rq[4]));
+            if (i < cnt) {
+                if constexpr (NR == 1) FA_RUN(FA_TRACE1, FA_DN0(rq[0]));
+                if constexpr (NR == 2) FA_RUN(FA_TRACE2, FA_DN0(rq[0]), FA_DN1(rq[1]));
+                if constexpr (NR == 3) FA_RUN(FA_TRACE3, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]));
+                if constexpr (NR == 4)
+                    FA_RUN(FA_TRACE4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]));
+                if constexpr (NR == 5)
+                    FA_RUN(FA_TRACE5, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_DN4(rq[4]));
+            }
 #undef FA_RUN
-            if (i >= cnt) break;
-            exact_batches++;
-            // Exact evaluation of the batch the loop stopped at.
-#pragma unroll
-            for (int u = 0; u < SPH_BATCH; u++) {
-                if (pass[u] >= 0) {
-                    // Sphere.Intersect objects.cs:112-121, literally.
-                    const f3 op = sub3(o, mk3(sp[u].x, sp[u].y, sp[u].z));
-                    const float c = dot3(op, op) - sp[u].w;
+            // Exact evaluation of the queued spheres, in index order (Sphere.Intersect
+            // objects.cs:112-121, literally).
+            const int nq = (int)((qaddr - q0) / FA_QUEUE_STRIDE);
+            candidates += nq;
+            for (int j = 0; __ballot(j < nq) != 0ull; j++) {
+                if (j < nq) {
+                    const int li = cand[j * 256 + threadIdx.x];
+                    const float4 sp = lds[li];
+                    const f3 op = sub3(o, xyz(sp));
+                    const float c = dot3(op, op) - sp.w;
                     float t;
                     if (SEC) {
                         const float x = dot3(r.sec_d, op);
                         if (sphere_maybe(x, r.sec_a * c) && sphere_root(x, c, r.sec_a, t) && t < best_t &&
                             t > RT_EPS) {
                             best_t = t;
-                            best_i = base + i + u;
+                            best_i = base + li;
                         }
                     }
 #pragma unroll
@@ -518,12 +530,12 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, const b
                         const float x = dot3(r.sh_d[l], op);
                         if (sphere_maybe(x, r.sh_a[l] * c) && sphere_root(x, c, r.sh_a[l], t) && t > RT_EPS &&
                             t < r.sh_dist[l])
-                            r.sh_first[l] = min(r.sh_first[l], cload(s.sph_orig, base + i + u));
+                            r.sh_first[l] = min(r.sh_first[l], s.sph_orig[base + li]);
                     }
                 }
             }
-            i += SPH_BATCH;
-            addr += SPH_BATCH * 16;
+            qaddr = q0;
+            if (i >= cnt) break;
         }
     }
     if (SEC) {
@@ -574,12 +586,12 @@ __device__ __forceinline__ f3 record_normal(const DevScene &s, int prim, int typ
 
 struct TestCount {
     int sph, pl, tri;
-    int exact;   // batches this wave sent to the exact code (wave-uniform)
+    int exact;   // (record, sphere) pairs this lane evaluated exactly
 };
 
 // One chunk of LC lights (plus the reflection ray when SEC) for one record.
 template <int LC, bool SEC>
-__device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, const bool single, const f3 hit,
+__device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, int *cand, const bool single, const f3 hit,
                                             const f3 view, const f3 normal, int l0, uint32_t &mask_word,
                                             Closest &sec_out, f3 &sec_dir, TestCount &tc)
 {
@@ -600,7 +612,7 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, cons
         r.sec.t = RT_FLT_MAX;
         r.sec.prim = INT_MAX;
     }
-    traverse<LC, SEC>(s, lds, single, hit, r, tc.exact);
+    traverse<LC, SEC>(s, lds, cand, single, hit, r, tc.exact);
 #pragma unroll
     for (int l = 0; l < LC; l++) {
         const bool occluded = r.sh_first[l] != INT_MAX;
@@ -628,6 +640,7 @@ template <bool SEC, int LCMAX>
 __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level)
 {
     __shared__ float4 lds[SPH_LDS_ENTRIES];
+    __shared__ int cand[QUEUE_INTS];
     __shared__ int blk[12];
     const int n = SEC ? f.cnt[2 * level] : f.cnt[2 * level + 1];
     const int ntiles = (n + 255) >> 8;
@@ -660,19 +673,19 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
         while (l0 < nl || (SEC && first)) {
             const int rem = nl - l0;
             if (LCMAX >= 4 && rem >= 4) {
-                if (SEC && first) trace_chunk<LCMAX >= 4 ? 4 : 2, true>(s, lds, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-                else trace_chunk<LCMAX >= 4 ? 4 : 2, false>(s, lds, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                if (SEC && first) trace_chunk<LCMAX >= 4 ? 4 : 2, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                else trace_chunk<LCMAX >= 4 ? 4 : 2, false>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
                 l0 += 4;
             } else if (rem >= 2) {
-                if (SEC && first) trace_chunk<2, true>(s, lds, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-                else trace_chunk<2, false>(s, lds, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                if (SEC && first) trace_chunk<2, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                else trace_chunk<2, false>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
                 l0 += 2;
             } else if (rem == 1) {
-                if (SEC && first) trace_chunk<1, true>(s, lds, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-                else trace_chunk<1, false>(s, lds, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                if (SEC && first) trace_chunk<1, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                else trace_chunk<1, false>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
                 l0 += 1;
             } else {
-                trace_chunk<0, true>(s, lds, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+                trace_chunk<0, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
             }
             first = false;
             if (l0 > 0 && ((l0 & 31) == 0 || l0 >= nl)) {
@@ -685,7 +698,7 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
             tc.pl += ltc.pl;
             tc.tri += ltc.tri;
         }
-        tc.exact += ltc.exact;
+        if (active) tc.exact += ltc.exact;
         if (SEC) {
             const bool child = active && sec.prim != INT_MAX;
             const f3 hit2 = add3(hit, scale3(sec_dir, sec.t));   // objects.cs:123,166,263
@@ -702,7 +715,8 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
         atomicAdd(&f.counters->plane_tests, (unsigned long long)wp);
         atomicAdd(&f.counters->triangle_tests, (unsigned long long)wt);
     }
-    if ((threadIdx.x & 63) == 0 && tc.exact) atomicAdd(&f.counters->exact_batches, (unsigned long long)tc.exact);
+    const int we = wave_sum(tc.exact);
+    if ((threadIdx.x & 63) == 0 && we) atomicAdd(&f.counters->exact_candidates, (unsigned long long)we);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -857,16 +871,16 @@ void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int
                        pixels);
 }
 
-void rtk_trace_level(const DevScene &s, const DevFrame &f, int level, int grid_blocks,
-                     hipStream_t stream)
+void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting, int grid_blocks,
+               hipStream_t stream)
 {
     const dim3 g(grid_blocks), b(256);
     if (s.nl >= 4) {
-        if (level < f.max_depth) hipLaunchKernelGGL((k_trace<true, 4>), g, b, 0, stream, s, f, level);
-        hipLaunchKernelGGL((k_trace<false, 4>), g, b, 0, stream, s, f, level);
+        if (reflecting) hipLaunchKernelGGL((k_trace<true, 4>), g, b, 0, stream, s, f, level);
+        else hipLaunchKernelGGL((k_trace<false, 4>), g, b, 0, stream, s, f, level);
     } else {
-        if (level < f.max_depth) hipLaunchKernelGGL((k_trace<true, 2>), g, b, 0, stream, s, f, level);
-        hipLaunchKernelGGL((k_trace<false, 2>), g, b, 0, stream, s, f, level);
+        if (reflecting) hipLaunchKernelGGL((k_trace<true, 2>), g, b, 0, stream, s, f, level);
+        else hipLaunchKernelGGL((k_trace<false, 2>), g, b, 0, stream, s, f, level);
     }
 }
 

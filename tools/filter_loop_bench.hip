@@ -5,7 +5,10 @@
 #include <cstdio>
 #include <cmath>
 #include <vector>
-#include "filter_asm.inc"
+#ifndef FA_INC
+#define FA_INC "filter_asm.inc"
+#endif
+#include FA_INC
 typedef float f4raw __attribute__((ext_vector_type(4)));
 #define CH 1024
 
@@ -14,6 +17,7 @@ __global__ void __launch_bounds__(256) k(const float4 *sph, int reps, float *out
 {
     __shared__ float4 lds[CH + FA_LDS_SLACK];
     __shared__ float pad[PAD > 0 ? PAD : 1];   // extra LDS to cap the workgroups per CU
+    __shared__ int cand[16 * 256];
     for (int i = threadIdx.x; i < CH + FA_LDS_SLACK; i += 256) lds[i] = sph[i];
     if (PAD > 0) pad[threadIdx.x % PAD] = 0.f;
     __syncthreads();
@@ -26,18 +30,16 @@ __global__ void __launch_bounds__(256) k(const float4 *sph, int reps, float *out
         int i = 0;
         const int cnt = CH;
         unsigned addr = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char *)lds;
+        const unsigned q0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char *)cand + 4u * threadIdx.x;
+        const unsigned qlim = q0 + 8 * 1024 + 1020;
+        unsigned qaddr = q0;
         while (i < cnt) {
-            f4raw sp[4];
-            int pass[4];
             asm volatile(FA_PRIMARY4_ASM
-                         : [i] "+s"(i), [addr] "+v"(addr), FA_SP0(sp[0]), FA_SP1(sp[1]), FA_SP2(sp[2]), FA_SP3(sp[3]),
-                           FA_ACC0(pass[0]), FA_ACC1(pass[1]), FA_ACC2(pass[2]), FA_ACC3(pass[3])
-                         : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), FA_FM(fm), [cnt] "s"(cnt)
+                         : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
+                         : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), FA_FM(fm), [cnt] "s"(cnt), [qlim] "s"(qlim)
                          : FA_PRIMARY4_CLOBBERS);
-            if (i >= cnt) break;
-            hits += (pass[0] >= 0) + (pass[1] >= 0) + (pass[2] >= 0) + (pass[3] >= 0) + (sp[0].x > 0);
-            i += 4;
-            addr += 64;
+            hits += (int)(qaddr - q0);
+            qaddr = q0;
         }
     }
     if (PAD > 0) hits += (int)pad[0];

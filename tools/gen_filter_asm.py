@@ -17,20 +17,24 @@ Register plan (VGPR numbers; b0..b3 = bank):
   v[60+4u : 63+4u]  trace: (opx b0, opy b1, opz b2, -c'' b3) of sphere u
   v76 v78 v80 v82   trace: |o-p|^2 accumulators (fmac: the accumulator's bank is free)
   v[84+4j] (b0), v[85+4j] (b1), j < 10   chain temporaries ta, tb
-  v86 v90 v94 v98 (b2)   verdict word of sphere u;  v87 their AND
+  v86+4m, m < 8 (b2)     verdict word of sphere m of the trip;  v87 their AND
+  v24, v77 v79 v81 v83   batch index and the four sphere indices for the queue append
+  s[98:99]               saved exec mask during the append
 
 A loop walks the staged spheres from index i in batches of 4, two batches per trip with the
-two register sets in ping-pong (the LDS reads of one batch fly while the other is computed),
-and LEAVES as soon as some lane's verdict for a batch is "could hit": it then returns the
-batch index, the four verdict words and the batch's sphere data (always in set 0), the C++
-caller runs the exact evaluation for that batch and re-enters at the next batch.  Entering
-costs the copies of the ray data into the planned registers, so it must be rare - and it is:
-a batch leaves only when one of its 4 spheres is in front of and near one of the wave's rays.
+two register sets in ping-pong (the LDS reads of one batch fly while the other is computed).
+When some lane's verdict for a batch is "could hit", the lanes concerned append the sphere's
+index to their own candidate queue in LDS (slot-major: slot s of thread t at qaddr0 + 1024*s
++ 4*t, so a wave's write is conflict-free) and the loop goes on; the C++ caller runs the exact
+evaluation over each lane's queue afterwards, in index order.  The loop leaves early only when
+some lane's queue could overflow in the next trip (its qaddr has reached qlim); the caller
+then drains the queues and re-enters at the returned index.  The verdicts of a whole trip
+(8 spheres) are ANDed into one word and tested with ONE compare and branch per trip.
 
 The sphere array in LDS holds {x, y, z, w} per entry: for the primary loop x,y,z = o - p and
 w = -c'' precomputed per frame; for the trace loops x,y,z = p and w = r*r.  Behind the last
-batch there must be 12 more entries with w = -inf (they never pass): the loop may run one
-batch past the end when it was entered at an odd batch, and it always reads one batch ahead.
+batch there must be 4 more entries (any finite or infinite values): the loop always reads one
+batch ahead.  The loop is entered at multiples of 8 spheres and cnt is a multiple of 8.
 """
 import os
 
@@ -42,7 +46,8 @@ OP = lambda u: 60 + 4 * u
 Q = lambda u: 76 + 2 * u
 TA = lambda j: 84 + 4 * j
 TB = lambda j: 85 + 4 * j
-ACC = lambda u: 86 + 4 * u
+ACC = lambda u, ph=0: 86 + 4 * (NB_ * ph + u)
+NB_ = 4
 ALL = 87
 NB = 4  # spheres per batch
 
@@ -63,7 +68,9 @@ def fma(d, a, b, c, na=False, nc=False):
     return f"v_fma_f32 v{d}, {'-' if na else ''}v{a}, v{b}, {'-' if nc else ''}v{c}"
 
 
-def filter_set(lines, K, trace, cur):
+def filter_set(lines, K, trace, cur, ph=None):
+    if ph is None:
+        ph = cur
     """Verdicts of the NB spheres in register set `cur` for K rays -> ACC(u), ALL."""
     src = OP if trace else SET[cur]
     if trace:
@@ -94,16 +101,19 @@ def filter_set(lines, K, trace, cur):
             lines.append(fma(TB(tmp[u, k]), TA(tmp[u, k]), TA(tmp[u, k]), src(u) + 3))
         for u in us:
             j = tmp[u, 0]
-            lines.append(f"v_or_b32 v{ACC(u)}, v{TB(j)}, v{TA(j)}")
+            lines.append(f"v_or_b32 v{ACC(u, ph)}, v{TB(j)}, v{TA(j)}")
             for k in range(1, K):
                 j = tmp[u, k]
-                check3(TB(j), ACC(u), TA(j))
+                check3(TB(j), ACC(u, ph), TA(j))
                 # (v | x') & acc
-                lines.append(f"v_bitop3_b32 v{ACC(u)}, v{TB(j)}, v{ACC(u)}, v{TA(j)} bitop3:0xc8")
-    lines.append(f"v_and_b32 v{ALL}, v{ACC(0)}, v{ACC(1)}")
-    lines.append(f"v_and_b32 v{ALL}, v{ALL}, v{ACC(2)}")
-    lines.append(f"v_and_b32 v{ALL}, v{ALL}, v{ACC(3)}")
-    lines.append(f"v_cmp_lt_i32 vcc, -1, v{ALL}")
+                lines.append(f"v_bitop3_b32 v{ACC(u, ph)}, v{TB(j)}, v{ACC(u, ph)}, v{TA(j)} bitop3:0xc8")
+    if ph == 0:
+        lines.append(f"v_and_b32 v{ALL}, v{ACC(0, ph)}, v{ACC(1, ph)}")
+    else:
+        lines.append(f"v_and_b32 v{ALL}, v{ALL}, v{ACC(0, ph)}")
+        lines.append(f"v_and_b32 v{ALL}, v{ALL}, v{ACC(1, ph)}")
+    lines.append(f"v_and_b32 v{ALL}, v{ALL}, v{ACC(2, ph)}")
+    lines.append(f"v_and_b32 v{ALL}, v{ALL}, v{ACC(3, ph)}")
 
 
 def loads(lines, which, byte_offset):
@@ -112,31 +122,53 @@ def loads(lines, which, byte_offset):
         lines.append(f"ds_read_b128 v[{r}:{r + 3}], %[addr] offset:{byte_offset + 16 * u}")
 
 
+IDX0 = 24
+IDX = lambda u: 77 + 2 * u
+QSTRIDE = 1024   # bytes between a thread's consecutive queue slots (256 threads x 4 B)
+
+
+def append_block(L):
+    """After both phases of a trip: lanes whose verdict for a sphere is 'could hit' queue its
+    index (8 spheres per trip, in index order)."""
+    L.append(f"v_cmp_lt_i32 vcc, -1, v{ALL}")
+    L.append("s_cbranch_vccz .LFA_NOAPP%=")
+    L.append("s_mov_b64 s[98:99], exec")
+    L.append(f"v_mov_b32 v{IDX0}, %[i]")
+    for ph in range(2):
+        for u in range(NB):
+            L.append("s_mov_b64 exec, s[98:99]")   # the compare must see every lane again
+            L.append(f"v_add_u32 v{IDX(0)}, {ph * NB + u}, v{IDX0}")
+            L.append(f"v_cmp_lt_i32 vcc, -1, v{ACC(u, ph)}")
+            L.append("s_and_b64 exec, s[98:99], vcc")
+            L.append(f"ds_write_b32 %[qaddr], v{IDX(0)}")
+            L.append(f"v_add_u32 %[qaddr], {QSTRIDE}, %[qaddr]")
+    L.append("s_mov_b64 exec, s[98:99]")
+    L.append("v_cmp_le_u32 vcc, %[qlim], %[qaddr]")
+    L.append("s_cbranch_vccnz .LFA_FULL%=")
+    L.append(".LFA_NOAPP%=:")
+
+
 def gen_loop(K, trace):
     L = []
     loads(L, 0, 0)
     L.append(".LFA_LOOP%=:")
     L.append("s_waitcnt lgkmcnt(0)")
     loads(L, 1, 16 * NB)
-    filter_set(L, K, trace, 0)
-    L.append("s_cbranch_vccnz .LFA_EVEN%=")
+    filter_set(L, K, trace, 0, 0)
     L.append("s_waitcnt lgkmcnt(0)")
     loads(L, 0, 32 * NB)
-    filter_set(L, K, trace, 1)
-    L.append("s_cbranch_vccnz .LFA_ODD%=")
+    filter_set(L, K, trace, 1, 1)
+    append_block(L)
     L.append(f"s_add_u32 %[i], %[i], {2 * NB}")
     L.append(f"v_add_u32 %[addr], {32 * NB}, %[addr]")
     L.append("s_cmp_lt_i32 %[i], %[cnt]")
     L.append("s_cbranch_scc1 .LFA_LOOP%=")
-    L.append("s_branch .LFA_EVEN%=")
-    L.append(".LFA_ODD%=:")
-    L.append("s_waitcnt lgkmcnt(0)")          # the read-ahead into set 0 must land before the copy
-    L.append(f"s_add_u32 %[i], %[i], {NB}")
-    L.append(f"v_add_u32 %[addr], {16 * NB}, %[addr]")
-    for u in range(NB):
-        for c in range(4):
-            L.append(f"v_mov_b32 v{SET[0](u) + c}, v{SET[1](u) + c}")
-    L.append(".LFA_EVEN%=:")
+    L.append("s_branch .LFA_DONE%=")
+    # A queue is (nearly) full: return the index of the next trip.
+    L.append(".LFA_FULL%=:")
+    L.append(f"s_add_u32 %[i], %[i], {2 * NB}")
+    L.append(f"v_add_u32 %[addr], {32 * NB}, %[addr]")
+    L.append(".LFA_DONE%=:")
     L.append("s_waitcnt lgkmcnt(0)")          # nothing of ours may still be in flight outside
     return L
 
@@ -144,7 +176,10 @@ def gen_loop(K, trace):
 def clobbers(K, trace):
     regs = set()
     for u in range(NB):
+        regs.update(range(SET[0](u), SET[0](u) + 4))
         regs.update(range(SET[1](u), SET[1](u) + 4))
+        regs.update((ACC(u, 0), ACC(u, 1), IDX(u)))
+    regs.add(IDX0)
     for j in range(2 * K):
         regs.update((TA(j), TB(j)))
     regs.add(ALL)
@@ -152,20 +187,23 @@ def clobbers(K, trace):
         for u in range(NB):
             regs.update(range(OP(u), OP(u) + 4))
             regs.add(Q(u))
-    regs -= {ACC(u) for u in range(NB)}
     return sorted(regs)
 
 
 def emit(name, K, trace):
     lines = gen_loop(K, trace)
-    out = [f"// {name}: {'trace' if trace else 'primary'} loop, {K} ray(s) per lane, "
-           f"{sum(1 for l in lines if l.startswith('v_')) - 16 - 1} VALU instructions per trip of {2 * NB} spheres"]
+    probe = []
+    filter_set(probe, K, trace, 0, 0)
+    filter_set(probe, K, trace, 1, 1)
+    valu = sum(1 for l in probe if l.startswith("v_")) + 2
+    out = [f"// {name}: {'trace' if trace else 'primary'} loop, {K} ray(s) per lane, {valu} VALU instructions per "
+           f"trip of {2 * NB} spheres when nothing is queued"]
     out.append(f"#define {name}_ASM \\")
     for l in lines:
         out.append(f'    "{l}\\n" \\')
     out[-1] = out[-1][:-2]
     cl = ", ".join(f'"v{r}"' for r in clobbers(K, trace))
-    out.append(f"#define {name}_CLOBBERS {cl}, \"vcc\", \"scc\", \"memory\"")
+    out.append(f"#define {name}_CLOBBERS {cl}, \"s98\", \"s99\", \"vcc\", \"scc\", \"memory\"")
     return out
 
 
@@ -181,11 +219,10 @@ def main():
     out.append(f'#define FA_O "{{v[{O}:{O + 3}]}}"')
     out.append(f'#define FA_K1 "{{v{K1}}}"')
     out.append(f'#define FA_FM "{{v{FM}}}"')
-    for u in range(NB):
-        out.append(f'#define FA_SP{u} "={{v[{SET[0](u)}:{SET[0](u) + 3}]}}"')
-    for u in range(NB):
-        out.append(f'#define FA_ACC{u} "={{v{ACC(u)}}}"')
-    out.append(f"#define FA_LDS_SLACK {3 * NB}   // never-pass entries required behind the last batch")
+    out.append(f"#define FA_QUEUE_STRIDE {QSTRIDE}   // bytes between consecutive queue slots of one thread")
+    out.append(f"#define FA_BATCH {NB}")
+    out.append(f"#define FA_TRIP {2 * NB}   // spheres per loop trip; the loop is entered at multiples of it")
+    out.append(f"#define FA_LDS_SLACK {NB}   // never-pass entries required behind the last batch")
     out.append("")
     out += emit("FA_PRIMARY4", 4, False)
     out.append("")

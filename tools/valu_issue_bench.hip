@@ -205,6 +205,36 @@
     "v_add3_u32 v44, v8, v9, v10\n v_add3_u32 v45, v8, v9, v10\n v_add3_u32 v46, v8, v9, v10\n v_add3_u32 v47, v8, v9, v10\n" \
     "v_add3_u32 v48, v8, v9, v10\n v_add3_u32 v49, v8, v9, v10\n v_add3_u32 v50, v8, v9, v10\n v_add3_u32 v51, v8, v9, v10\n" \
     "v_add3_u32 v52, v8, v9, v10\n v_add3_u32 v53, v8, v9, v10\n v_add3_u32 v54, v8, v9, v10\n v_add3_u32 v55, v8, v9, v10\n"
+#define BODY_L_NEG0 \
+    "v_fma_f32 v40, -v9, v12, v14\n v_fma_f32 v44, -v9, v12, v14\n v_fma_f32 v48, -v9, v12, v14\n v_fma_f32 v52, -v9, v12, v14\n" \
+    "v_fma_f32 v56, -v9, v12, v14\n v_fma_f32 v60, -v9, v12, v14\n v_fma_f32 v64, -v9, v12, v14\n v_fma_f32 v68, -v9, v12, v14\n" \
+    "v_fma_f32 v40, -v9, v12, v14\n v_fma_f32 v44, -v9, v12, v14\n v_fma_f32 v48, -v9, v12, v14\n v_fma_f32 v52, -v9, v12, v14\n" \
+    "v_fma_f32 v56, -v9, v12, v14\n v_fma_f32 v60, -v9, v12, v14\n v_fma_f32 v64, -v9, v12, v14\n v_fma_f32 v68, -v9, v12, v14\n"
+#define BODY_L_POS0 \
+    "v_fma_f32 v40, v9, v12, v14\n v_fma_f32 v44, v9, v12, v14\n v_fma_f32 v48, v9, v12, v14\n v_fma_f32 v52, v9, v12, v14\n" \
+    "v_fma_f32 v56, v9, v12, v14\n v_fma_f32 v60, v9, v12, v14\n v_fma_f32 v64, v9, v12, v14\n v_fma_f32 v68, v9, v12, v14\n" \
+    "v_fma_f32 v40, v9, v12, v14\n v_fma_f32 v44, v9, v12, v14\n v_fma_f32 v48, v9, v12, v14\n v_fma_f32 v52, v9, v12, v14\n" \
+    "v_fma_f32 v56, v9, v12, v14\n v_fma_f32 v60, v9, v12, v14\n v_fma_f32 v64, v9, v12, v14\n v_fma_f32 v68, v9, v12, v14\n"
+#define BODY_L_NEG0_D3 \
+    "v_fma_f32 v43, -v9, v12, v14\n v_fma_f32 v47, -v9, v12, v14\n v_fma_f32 v51, -v9, v12, v14\n v_fma_f32 v55, -v9, v12, v14\n" \
+    "v_fma_f32 v59, -v9, v12, v14\n v_fma_f32 v63, -v9, v12, v14\n v_fma_f32 v67, -v9, v12, v14\n v_fma_f32 v71, -v9, v12, v14\n" \
+    "v_fma_f32 v43, -v9, v12, v14\n v_fma_f32 v47, -v9, v12, v14\n v_fma_f32 v51, -v9, v12, v14\n v_fma_f32 v55, -v9, v12, v14\n" \
+    "v_fma_f32 v59, -v9, v12, v14\n v_fma_f32 v63, -v9, v12, v14\n v_fma_f32 v67, -v9, v12, v14\n v_fma_f32 v71, -v9, v12, v14\n"
+#define BODY_L_POS0_D3 \
+    "v_fma_f32 v43, v9, v12, v14\n v_fma_f32 v47, v9, v12, v14\n v_fma_f32 v51, v9, v12, v14\n v_fma_f32 v55, v9, v12, v14\n" \
+    "v_fma_f32 v59, v9, v12, v14\n v_fma_f32 v63, v9, v12, v14\n v_fma_f32 v67, v9, v12, v14\n v_fma_f32 v71, v9, v12, v14\n" \
+    "v_fma_f32 v43, v9, v12, v14\n v_fma_f32 v47, v9, v12, v14\n v_fma_f32 v51, v9, v12, v14\n v_fma_f32 v55, v9, v12, v14\n" \
+    "v_fma_f32 v59, v9, v12, v14\n v_fma_f32 v63, v9, v12, v14\n v_fma_f32 v67, v9, v12, v14\n v_fma_f32 v71, v9, v12, v14\n"
+#define BODY_L_CHAIN \
+    "v_fma_f32 v40, -v9, v12, v14\n v_fma_f32 v44, -v9, v12, v14\n v_fma_f32 v48, -v9, v12, v14\n v_fma_f32 v52, -v9, v12, v14\n" \
+    "v_fma_f32 v56, -v9, v12, v14\n v_fma_f32 v60, -v9, v12, v14\n v_fma_f32 v64, -v9, v12, v14\n v_fma_f32 v68, -v9, v12, v14\n" \
+    "v_fma_f32 v41, -v10, v13, v40\n v_fma_f32 v45, -v10, v13, v44\n v_fma_f32 v49, -v10, v13, v48\n v_fma_f32 v53, -v10, v13, v52\n" \
+    "v_fma_f32 v57, -v10, v13, v56\n v_fma_f32 v61, -v10, v13, v60\n v_fma_f32 v65, -v10, v13, v64\n v_fma_f32 v69, -v10, v13, v68\n"
+#define BODY_L_SQ \
+    "v_fma_f32 v41, v40, v40, v15\n v_fma_f32 v45, v44, v44, v15\n v_fma_f32 v49, v48, v48, v15\n v_fma_f32 v53, v52, v52, v15\n" \
+    "v_fma_f32 v57, v56, v56, v15\n v_fma_f32 v61, v60, v60, v15\n v_fma_f32 v65, v64, v64, v15\n v_fma_f32 v69, v68, v68, v15\n" \
+    "v_fma_f32 v41, v40, v40, v15\n v_fma_f32 v45, v44, v44, v15\n v_fma_f32 v49, v48, v48, v15\n v_fma_f32 v53, v52, v52, v15\n" \
+    "v_fma_f32 v57, v56, v56, v15\n v_fma_f32 v61, v60, v60, v15\n v_fma_f32 v65, v64, v64, v15\n v_fma_f32 v69, v68, v68, v15\n"
 
 #define CLOBBERS "v8","v9","v10","v11","v12","v13","v14","v15","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67","v68","v69","v70","v71","s20","s21","s22","s23","vcc"
 
@@ -258,6 +288,12 @@ KERNEL(k_bitop3_conf, BODY_BITOP3_CONF)
 KERNEL(k_or_conf, BODY_OR_CONF)
 KERNEL(k_sub_conf, BODY_SUB_CONF)
 KERNEL(k_add3u, BODY_ADD3U)
+KERNEL(k_l_neg0, BODY_L_NEG0)
+KERNEL(k_l_pos0, BODY_L_POS0)
+KERNEL(k_l_neg0_d3, BODY_L_NEG0_D3)
+KERNEL(k_l_pos0_d3, BODY_L_POS0_D3)
+KERNEL(k_l_chain, BODY_L_CHAIN)
+KERNEL(k_l_sq, BODY_L_SQ)
 
 typedef void (*kern_t)(float *, int);
 
@@ -288,6 +324,7 @@ int main()
         {"v_fma_f32 v,v,v,v", k_fma_vvv}, {"v_pk_mul_f32 v,v,v", k_pkmul_vv},
         {"v_pk_mul_f32 v,v,s(bcast)", k_pkmul_vs}, {"v_pk_fma_f32 v,v,v,v", k_pkfma_vvv},
         {"v_cmp_ge_f32", k_cmp}, {"v_max3_f32", k_max3},
+        {"v_fma_f32 v40, -v9, v12, v14 ...", k_l_neg0}, {"v_fma_f32 v40, v9, v12, v14 ...", k_l_pos0}, {"v_fma_f32 v43, -v9, v12, v14 ...", k_l_neg0_d3}, {"v_fma_f32 v43, v9, v12, v14 ...", k_l_pos0_d3}, {"v_fma_f32 v40, -v9, v12, v14 ...", k_l_chain}, {"v_fma_f32 v41, v40, v40, v15 ...", k_l_sq}, 
         {"v_fmac_f32 v40, v8, v12", k_fmac_s01}, {"v_fmac_f32 v40, v8, v9", k_fmac_d0}, {"v_fmac_f32 v40, v8, v9", k_fmac_d0i}, {"v_fmac_f32 v40, v9, v8", k_fmac_d1i}, {"v_fmac_f32 v40, v9, v10", k_fmac_ok}, {"v_fma_f32 v40, v9, v9, v10", k_fma_sq}, {"v_fma_f32 v40, v9, v9, v13", k_fma_sq_conf}, {"v_bitop3_b32 v40, v8, v9, v10 bitop3:0xc8", k_bitop3}, {"v_bitop3_b32 v40, v8, v12, v10 bitop3:0xc8", k_bitop3_conf}, {"v_or_b32 v40, v8, v12", k_or_conf}, {"v_sub_f32 v40, v8, v12", k_sub_conf}, {"v_add3_u32 v40, v8, v9, v10", k_add3u}, 
         {"v_fma src0,src1 same bank", k_fma_2bank}, {"v_fma src1,src2 same bank", k_fma_2bankb}, {"v_fma 3 banks", k_fma_noconf}, {"v_mul src0,src1 same bank", k_mul_2bank},
         {"v_min_f32 vD, vA, vB", k_body_min_vv}, {"v_max_f32 vD, vA, vB", k_body_max_vv}, {"v_sub_f32 vD, vA, vB", k_body_sub_vv}, {"v_min_f32_e64 vD, vA, -vB", k_body_min_neg}, {"v_mul_f32_e64 vD, vA, -|vB|", k_body_mul_abs}, {"v_fma_f32 vD, vA, vB, -vC", k_body_fma_neg}, {"v_fma_f32 vD, vA, s20, vC", k_body_fma_s}, {"v_fma_f32 vD, vA, vB, 1.0", k_body_fma_k}, {"v_and_b32 vD, vA, vB", k_body_and}, {"v_or_b32 vD, vA, vB", k_body_or}, {"v_cndmask_b32 vD, vA, vB, vcc", k_body_cndmask}, {"v_mov_b32 vD, vA", k_body_mov}, {"v_subrev_f32 vD, s21, vB", k_body_subrev_s}, {"v_fmac_f32 vD, vA, vB", k_body_mac}};
