@@ -165,3 +165,66 @@ def test_errors_follow_the_convention(ctx):
     with pytest.raises(RtError):
         fresh.render(Camera(), 8, 8, 99)
     fresh.close()
+
+
+def test_config3_full_size_sampled_rows(ctx, oracle):
+    """Config 3 at its full 3840x2160, 4 bounces: every 45th row against the oracle, and the
+    frame-level invariants (every pixel written, counters consistent)."""
+    fs = scene_1k().flatten()
+    ctx.set_scene(fs)
+    cam, w, h, depth = Camera(), 3840, 2160, 4
+    gpu = ctx.render(cam, w, h, depth)
+    st = ctx.stats()
+    assert st["rays_primary"] == w * h
+    assert st["rays_shadow"] == st["shaded_hits"] * fs.num_lights
+    assert st["shaded_hits"] >= w * h  # closed box: every primary ray hits something
+    ref, _ = oracle.render(fs, cam, w, h, max_depth=depth, row_step=45)
+    rows = np.arange(0, h, 45)
+    assert_parity(gpu[rows], ref[rows], "config 3 sampled rows")
+    # idempotence: a second frame on the same context is identical
+    assert np.array_equal(ctx.render(cam, w, h, depth), gpu)
+
+
+def test_config4_resolution_row_blocks(ctx, oracle):
+    """Config 4's 7680x4320 frame as eight 540-row blocks (the 8-GPU partition, rendered one
+    after the other here): blocks tile the frame and sampled rows match the oracle."""
+    import torch
+    fs = scene_1k().flatten()
+    ctx.set_scene(fs)
+    cam, w, h, depth = Camera(), 7680, 4320, 4
+    frame = torch.empty((h, w), dtype=torch.int32, device="cuda")
+    for r in range(8):
+        y0, y1 = 540 * r, 540 * (r + 1)
+        ctx.render_rows_device(cam, w, h, y0, y1, depth, frame[y0:y1].data_ptr(), 0)
+        torch.cuda.synchronize()
+    gpu = frame.cpu().numpy()
+    rows = np.arange(7, h, 540)  # one row inside every block
+    ref, _ = oracle.render(fs, cam, w, h, max_depth=depth, rows=(7, h), row_step=540)
+    assert_parity(gpu[rows], ref[rows], "config 4 row blocks")
+
+
+def test_config5_64k_spheres_16_lights_depth8(ctx, oracle):
+    """Config 5's scene (65536 spheres in 64 LDS chunks, 16 lights, 8 bounces) at a size the
+    oracle finishes in seconds."""
+    from raytracer_amd import scene_64k
+    fs = scene_64k().flatten()
+    gpu, ref, cnt = both(ctx, oracle, fs, Camera(), 64, 36, 8)
+    assert_parity(gpu, ref, "64k spheres")
+    st = ctx.stats()
+    for k in ("rays_shadow", "rays_secondary", "shaded_hits", "sphere_tests", "plane_tests"):
+        assert st[k] == cnt[k], k
+
+
+def test_two_device_states_split_rows_and_gather(oracle):
+    """rt_create with two device entries (the same GPU twice on a one-GPU box): the frame is
+    split into two row blocks, the second is gathered into the first device's frame."""
+    fs = default_scene().flatten()
+    cam = Camera()
+    with RenderContext([0, 0]) as two:
+        two.set_scene(fs)
+        for (w, h) in [(200, 150), (64, 33)]:
+            gpu = two.render(cam, w, h, 5)
+            ref, _ = oracle.render(fs, cam, w, h, max_depth=5)
+            assert np.array_equal(gpu, ref), (w, h)
+        assert two.stats()["num_devices"] == 2
+        assert two.stats()["rays_primary"] == 64 * 33
