@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -24,10 +25,8 @@ struct DeviceState {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {};  // begin, after primary, after trace, after shade, after gather copy
-    hipStream_t side = nullptr;             // second stream: plain-surface traces run beside
-    hipEvent_t fork[RT_MAX_DEPTH + 2] = {}; // the reflection chain (see enqueue_rows)
-    hipEvent_t join = nullptr;
     int num_cus = 256;
+    int resident_blocks = 0, resident_nl = -1;   // k_trace_levels workgroups resident at once
 
     // scene
     DevScene scene{};
@@ -115,6 +114,7 @@ void free_frame(DeviceState &d)
     if (d.frame.mask) (void)hipFree(d.frame.mask);
     if (d.frame.cnt) (void)hipFree(d.frame.cnt);
     if (d.frame.counters) (void)hipFree(d.frame.counters);
+    if (d.frame.sched) (void)hipFree(d.frame.sched);
     if (d.out) (void)hipFree(d.out);
     d.frame = DevFrame{};
     d.out = nullptr;
@@ -316,6 +316,7 @@ int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
         d.cap_levels = levels + 1;
     }
     if (!d.frame.counters) HIP_TRY(ctx, hipMalloc((void **)&d.frame.counters, sizeof(DevCounters)));
+    if (!d.frame.sched) HIP_TRY(ctx, hipMalloc((void **)&d.frame.sched, sizeof(DevSched)));
     d.frame.P = P;
     d.frame.slots = (int)slots;
     d.frame.max_depth = max_depth;
@@ -340,6 +341,20 @@ int check_render_args(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_d
     return RT_OK;
 }
 
+// After the device has finished a frame: did every workgroup of k_trace_levels see the
+// level it waited for?  (A set flag means the frame is incomplete.)
+int check_schedule(rt_ctx *ctx, DeviceState &d)
+{
+    static_assert(RT_DEV_MAX_LEVELS >= RT_MAX_DEPTH + 2, "DevSched holds one entry per level");
+    if (!d.frame.sched) return RT_OK;
+    DevSched sc;
+    HIP_TRY(ctx, hipMemcpy(&sc, d.frame.sched, sizeof sc, hipMemcpyDeviceToHost));
+    if (sc.error)
+        return fail(ctx, RT_ERR_HIP, "device %d: the level schedule stalled at level %d; the frame is incomplete",
+                    d.device, sc.open_level);
+    return RT_OK;
+}
+
 // Enqueue the whole frame pipeline for rows [y0, y1) on device state d.
 int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h, int y0, int y1,
                  int max_depth, int32_t *dev_pixels, hipStream_t stream)
@@ -357,28 +372,30 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     const DevFrame &f = d.frame;
     HIP_TRY(ctx, hipMemsetAsync(f.cnt, 0, 2 * (size_t)(max_depth + 2) * sizeof(int), stream));
     HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, sizeof(DevCounters), stream));
+    HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, sizeof(DevSched), stream));
     d.timed = ctx->profiling && stream == d.stream;
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
     const int blocks = std::max(1, std::min((P + 255) / 256, d.num_cus * 8));
     rtk_setup_camera(d.scene, dc, d.sph_cam, d.sph_cam_c, stream);
     rtk_primary(d.scene, dc, f, dev_pixels, blocks, stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[1], stream));
-    // Two dependency chains: level k+1's records exist once level k's reflecting records
-    // (queue A) are traced, so A0 -> A1 -> ... is serial and its deep levels are tiny
-    // launches that cannot fill the chip; the plain records of a level (queue B, most of
-    // the work, no successors) only need that level's records.  B_k therefore runs on a
-    // second stream beside A_k, A_{k+1}, ... and the small launches hide under the big ones.
-    HIP_TRY(ctx, hipEventRecord(d.fork[0], stream));
-    for (int k = 0; k <= max_depth; k++) {
-        HIP_TRY(ctx, hipStreamWaitEvent(d.side, d.fork[k], 0));
-        rtk_trace(d.scene, f, k, false, blocks, d.side);
-        if (k < max_depth) {
-            rtk_trace(d.scene, f, k, true, blocks, stream);
-            HIP_TRY(ctx, hipEventRecord(d.fork[k + 1], stream));
+    // RT_HIP_LEVEL_KERNELS=1 (profiling aid): one launch per queue per level on this stream,
+    // so that a kernel trace shows what each level costs on its own.
+    static const bool level_kernels = getenv("RT_HIP_LEVEL_KERNELS") != nullptr;
+    if (level_kernels) {
+        for (int k = 0; k <= max_depth; k++) {
+            rtk_trace(d.scene, f, k, false, blocks, stream);
+            if (k < max_depth) rtk_trace(d.scene, f, k, true, blocks, stream);
         }
+    } else {
+        // Every level in one launch of resident workgroups (k_trace_levels).
+        if (d.resident_nl != d.scene.nl) {
+            d.resident_blocks = rtk_trace_levels_resident_blocks(d.scene.nl, d.num_cus);
+            d.resident_nl = d.scene.nl;
+        }
+        const int tiles0 = (P + 255) / 256;
+        rtk_trace_levels(d.scene, f, std::max(1, std::min(2 * tiles0, d.resident_blocks)), stream);
     }
-    HIP_TRY(ctx, hipEventRecord(d.join, d.side));
-    HIP_TRY(ctx, hipStreamWaitEvent(stream, d.join, 0));
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[2], stream));
     for (int k = max_depth; k >= 0; k--) rtk_shade_level(d.scene, f, k, dev_pixels, blocks, stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[3], stream));
@@ -429,10 +446,6 @@ int rt_create(rt_ctx **out, const int *device_ids, int n_devices)
         }
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipEventCreate(&d.ev[k]);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking);
-        for (int k = 0; k < RT_MAX_DEPTH + 2 && e == hipSuccess; k++)
-            e = hipEventCreateWithFlags(&d.fork[k], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&d.join, hipEventDisableTiming);
         if (e != hipSuccess) {
             int rc = fail(nullptr, RT_ERR_HIP, "device %d setup failed: %s", d.device, hipGetErrorString(e));
             rt_destroy(ctx);
@@ -467,10 +480,6 @@ void rt_destroy(rt_ctx *ctx)
         free_frame(d);
         for (int k = 0; k < 5; k++)
             if (d.ev[k]) (void)hipEventDestroy(d.ev[k]);
-        for (int k = 0; k < RT_MAX_DEPTH + 2; k++)
-            if (d.fork[k]) (void)hipEventDestroy(d.fork[k]);
-        if (d.join) (void)hipEventDestroy(d.join);
-        if (d.side) (void)hipStreamSynchronize(d.side), (void)hipStreamDestroy(d.side);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
     if (ctx->staging) (void)hipHostFree(ctx->staging);
@@ -639,6 +648,7 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, in
             if (hipEventElapsedTime(&ms, d.ev[3], d.ev[4]) == hipSuccess)
                 ctx->gather_ms = std::max(ctx->gather_ms, (double)ms);
         }
+        if (d.last_P > 0 && (rc = check_schedule(ctx, d)) != RT_OK) return rc;
     }
     // D2H into pinned staging, then into the caller's (pageable) array.
     const auto t0 = std::chrono::steady_clock::now();
@@ -665,6 +675,8 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out)
         DevCounters c{};
         HIP_TRY(ctx, hipMemcpy(cnt.data(), d.frame.cnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(&c, d.frame.counters, sizeof c, hipMemcpyDeviceToHost));
+        int rc = check_schedule(ctx, d);
+        if (rc != RT_OK) return rc;
         uint64_t hits = 0, secondary = 0;
         for (int k = 0; k <= d.last_depth; k++) {
             hits += (uint64_t)cnt[2 * k] + (uint64_t)cnt[2 * k + 1];

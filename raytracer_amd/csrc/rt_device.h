@@ -79,6 +79,16 @@ struct DevCounters {
     unsigned long long exact_candidates;   // (ray origin, sphere) pairs evaluated exactly
 };
 
+// Tile schedule of k_trace_levels (rt_kernels.hip), zeroed before every render call.
+#define RT_DEV_MAX_LEVELS 18   // RT_MAX_DEPTH + 2
+struct DevSched {
+    int next_a[RT_DEV_MAX_LEVELS];   // next unclaimed tile of level k's reflecting records
+    int next_b[RT_DEV_MAX_LEVELS];   // ... of its plain records
+    int done_a[RT_DEV_MAX_LEVELS];   // finished reflecting tiles of level k
+    int open_level;                  // levels <= open_level have their final record counts
+    int error;                       // set when a workgroup gave up waiting for a level
+};
+
 // Hit records: the bounce stack of every pixel, kept in HBM.  Level k of the frame
 // owns slots [k*P, (k+1)*P) (P = pixels of the render call).  Records whose surface
 // needs a reflection trace ("A": specular != 0 and k < max_depth) are appended from
@@ -96,6 +106,7 @@ struct DevFrame {
     uint32_t *mask;
     int *cnt;              // cnt[2*k] = A records of level k, cnt[2*k+1] = B records
     DevCounters *counters;
+    DevSched *sched;
     int P;                 // pixels of this render call
     int slots;             // P * (max_depth + 1)
     int max_depth;
@@ -110,5 +121,9 @@ void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int
 // reflecting: the level's records that need a reflection trace (queue A) or the others (B).
 void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting, int grid_blocks,
                hipStream_t stream);
+// Every level in one launch; grid_blocks = workgroups resident at once on the device
+// (rtk_trace_levels_resident_blocks), fewer if the frame has fewer tiles.
+int rtk_trace_levels_resident_blocks(int nl, int num_cus);
+void rtk_trace_levels(const DevScene &s, const DevFrame &f, int grid_blocks, hipStream_t stream);
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
                      int grid_blocks, hipStream_t stream);

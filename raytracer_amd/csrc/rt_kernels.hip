@@ -633,9 +633,87 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, int 
     }
 }
 
+// One tile = 256 consecutive records of one queue of one level, one record per lane.
 // SEC: the records of the level that need a reflection trace (queue "A") or the others
 // ("B").  LCMAX: lights handled per scene walk (2 or 4); with few lights the 2-light
-// instance is used, which needs far fewer registers.
+// instance is used, which needs far fewer registers.  n = records in the queue.
+// Every thread of the workgroup must call it (barriers inside).
+template <bool SEC, int LCMAX>
+__device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f, float4 *lds, int *cand, int *blk,
+                                           const bool single, const int level, const int tile, const int n,
+                                           TestCount &tc)
+{
+    const int i = tile * 256 + threadIdx.x;
+    const bool active = i < n;
+    const int ii = active ? i : n - 1;
+    const int slot = SEC ? (level * f.P + ii) : ((level + 1) * f.P - 1 - ii);
+    const float4 ra = f.recA[slot], rb = f.recB[slot];
+    const f3 hit = xyz(ra), view = xyz(rb);
+    const int prim = __float_as_int(ra.w);
+    const int type = __float_as_int(cload(s.mat, 3 * prim + 1).w) & RT_MF_TYPE_MASK;
+    const f3 normal = record_normal(s, prim, type, hit);
+
+    Closest sec = {RT_FLT_MAX, INT_MAX};
+    f3 sec_dir = mk3(0.0f, 0.0f, 0.0f);
+    TestCount ltc = {0, 0, 0, 0};
+    uint32_t word = 0;
+    int l0 = 0;
+    bool first = true;
+    const int nl = s.nl;
+    // Lights in chunks of 4 / 2 / 1; the reflection ray rides with the first chunk.
+    while (l0 < nl || (SEC && first)) {
+        const int rem = nl - l0;
+        if (LCMAX >= 4 && rem >= 4) {
+            if (SEC && first) trace_chunk<LCMAX >= 4 ? 4 : 2, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            else trace_chunk<LCMAX >= 4 ? 4 : 2, false>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            l0 += 4;
+        } else if (rem >= 2) {
+            if (SEC && first) trace_chunk<2, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            else trace_chunk<2, false>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            l0 += 2;
+        } else if (rem == 1) {
+            if (SEC && first) trace_chunk<1, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            else trace_chunk<1, false>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            l0 += 1;
+        } else {
+            trace_chunk<0, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+        }
+        first = false;
+        if (l0 > 0 && ((l0 & 31) == 0 || l0 >= nl)) {
+            if (active) f.mask[(size_t)((l0 - 1) >> 5) * (size_t)f.slots + slot] = word;
+            word = 0;
+        }
+    }
+    if (active) {
+        tc.sph += ltc.sph;
+        tc.pl += ltc.pl;
+        tc.tri += ltc.tri;
+        tc.exact += ltc.exact;
+    }
+    if (SEC) {
+        const bool child = active && sec.prim != INT_MAX;
+        const f3 hit2 = add3(hit, scale3(sec_dir, sec.t));   // objects.cs:123,166,263
+        if (active) f.refl[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const bool rv[1] = {child};
+        const int rp[1] = {child ? sec.prim : 0}, rparent[1] = {slot};
+        const f3 rh[1] = {hit2}, rd[1] = {sec_dir};
+        push_records<1>(f, s, level + 1, blk, rv, rp, rh, rd, rparent);
+    }
+}
+
+__device__ __forceinline__ void flush_test_counts(const DevFrame &f, const TestCount &tc)
+{
+    const int ws = wave_sum(tc.sph), wp = wave_sum(tc.pl), wt = wave_sum(tc.tri), we = wave_sum(tc.exact);
+    if ((threadIdx.x & 63) == 0) {
+        if (ws) atomicAdd(&f.counters->sphere_tests, (unsigned long long)ws);
+        if (wp) atomicAdd(&f.counters->plane_tests, (unsigned long long)wp);
+        if (wt) atomicAdd(&f.counters->triangle_tests, (unsigned long long)wt);
+        if (we) atomicAdd(&f.counters->exact_candidates, (unsigned long long)we);
+    }
+}
+
+// One queue of one level per launch (the form a kernel trace can attribute time to; the
+// frame pipeline normally uses k_trace_levels below).
 template <bool SEC, int LCMAX>
 __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level)
 {
@@ -651,72 +729,122 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
     }
     TestCount tc = {0, 0, 0, 0};
     // Workgroup-uniform trip count: the sphere chunks are staged between barriers.
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int i = tile * 256 + threadIdx.x;
-        const bool active = i < n;
-        const int ii = active ? i : n - 1;
-        const int slot = SEC ? (level * f.P + ii) : ((level + 1) * f.P - 1 - ii);
-        const float4 ra = f.recA[slot], rb = f.recB[slot];
-        const f3 hit = xyz(ra), view = xyz(rb);
-        const int prim = __float_as_int(ra.w);
-        const int type = __float_as_int(cload(s.mat, 3 * prim + 1).w) & RT_MF_TYPE_MASK;
-        const f3 normal = record_normal(s, prim, type, hit);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+        trace_tile<SEC, LCMAX>(s, f, lds, cand, blk, single, level, tile, n, tc);
+    flush_test_counts(f, tc);
+}
 
-        Closest sec = {RT_FLT_MAX, INT_MAX};
-        f3 sec_dir = mk3(0.0f, 0.0f, 0.0f);
-        TestCount ltc = {0, 0, 0, 0};
-        uint32_t word = 0;
-        int l0 = 0;
-        bool first = true;
-        const int nl = s.nl;
-        // Lights in chunks of 4 / 2 / 1; the reflection ray rides with the first chunk.
-        while (l0 < nl || (SEC && first)) {
-            const int rem = nl - l0;
-            if (LCMAX >= 4 && rem >= 4) {
-                if (SEC && first) trace_chunk<LCMAX >= 4 ? 4 : 2, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-                else trace_chunk<LCMAX >= 4 ? 4 : 2, false>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-                l0 += 4;
-            } else if (rem >= 2) {
-                if (SEC && first) trace_chunk<2, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-                else trace_chunk<2, false>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-                l0 += 2;
-            } else if (rem == 1) {
-                if (SEC && first) trace_chunk<1, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-                else trace_chunk<1, false>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-                l0 += 1;
-            } else {
-                trace_chunk<0, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+// ---------------------------------------------------------------------------------------
+// trace_levels: every level of the frame in ONE launch of resident workgroups that take
+// tiles from a shared schedule (DevSched).  Level k+1's records exist once all reflecting
+// tiles ("A") of level k are done, so the A tiles form a serial chain of ever smaller
+// levels; the plain tiles ("B", most of the work) have no successors.  A workgroup takes
+// the next A tile of the newest open level when there is one, otherwise a B tile of any
+// open level, and sleeps only when neither exists while A tiles are still in flight.  The
+// chip therefore stays full across level boundaries, where separate launches per level
+// leave it to a shrinking tail of workgroups.
+//
+// Protocol: after a workgroup barrier, thread 0 of a workgroup that finished an A tile
+// fences at device scope and counts the tile as done; the one that counts the level's last
+// tile publishes open_level = k+1.  Takers (thread 0) read open_level and the record counts
+// with device-scope atomic loads and fence before the workgroup barrier that hands the job
+// to the other lanes.  The chain ends at the first
+// open level without A records (level max_depth never has any); a workgroup leaves when
+// the chain has ended and no B tile is left to claim.  A workgroup that waits longer than
+// SCHED_SPIN_LIMIT polls for a level to open sets sched->error and leaves (the host
+// reports it) so that no launch can spin forever.
+// ---------------------------------------------------------------------------------------
+#define SCHED_JOB_EXIT 0
+#define SCHED_JOB_A 1
+#define SCHED_JOB_B 2
+#define SCHED_SPIN_LIMIT (1u << 21)   // x ~14 us per poll: ~30 s
+
+__device__ __forceinline__ int sched_load(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int LCMAX>
+__global__ void __launch_bounds__(256) k_trace_levels(DevScene s, DevFrame f)
+{
+    __shared__ float4 lds[SPH_LDS_ENTRIES];
+    __shared__ int cand[QUEUE_INTS];
+    __shared__ int blk[12];
+    __shared__ int job[4];
+    DevSched *const sc = f.sched;
+    const int D = f.max_depth;
+    const bool single = s.ns_padded <= SPH_CHUNK;
+    bool staged = false;
+    TestCount tc = {0, 0, 0, 0};
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int kind = SCHED_JOB_EXIT, lvl = 0, tile = 0, n = 0;
+            unsigned spins = 0;
+            for (;;) {
+                const int open = __hip_atomic_load(&sc->open_level, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                const int na = open < D ? sched_load(&f.cnt[2 * open]) : 0;
+                const int tiles_a = (na + 255) >> 8;
+                if (tiles_a > 0 && sched_load(&sc->next_a[open]) < tiles_a) {
+                    const int t = atomicAdd(&sc->next_a[open], 1);
+                    if (t < tiles_a) {
+                        kind = SCHED_JOB_A, lvl = open, tile = t, n = na;
+                        break;
+                    }
+                }
+                const int top = open < D ? open : D;
+                for (int j = 0; j <= top && kind == SCHED_JOB_EXIT; j++) {
+                    const int nb = sched_load(&f.cnt[2 * j + 1]);
+                    const int tiles_b = (nb + 255) >> 8;
+                    if (sched_load(&sc->next_b[j]) < tiles_b) {
+                        const int t = atomicAdd(&sc->next_b[j], 1);
+                        if (t < tiles_b) kind = SCHED_JOB_B, lvl = j, tile = t, n = nb;
+                    }
+                }
+                if (kind != SCHED_JOB_EXIT) break;
+                if (tiles_a == 0) break;   // the chain has ended and every B tile is taken: leave
+                // A tiles of level `open` are in flight: wait for the next level to open.
+                while (sched_load(&sc->open_level) == open && spins < SCHED_SPIN_LIMIT) {
+                    spins++;
+                    __builtin_amdgcn_s_sleep(127);
+                    __builtin_amdgcn_s_sleep(127);
+                    __builtin_amdgcn_s_sleep(127);
+                    __builtin_amdgcn_s_sleep(127);
+                }
+                if (spins >= SCHED_SPIN_LIMIT) {
+                    atomicExch(&sc->error, 1);
+                    break;
+                }
             }
-            first = false;
-            if (l0 > 0 && ((l0 & 31) == 0 || l0 >= nl)) {
-                if (active) f.mask[(size_t)((l0 - 1) >> 5) * (size_t)f.slots + slot] = word;
-                word = 0;
+            __threadfence();   // acquire: what other workgroups published before open_level moved
+            job[0] = kind;
+            job[1] = lvl;
+            job[2] = tile;
+            job[3] = n;
+        }
+        __syncthreads();
+        const int kind = job[0], lvl = job[1], tile = job[2], n = job[3];
+        if (kind == SCHED_JOB_EXIT) break;
+        if (single && !staged) {
+            stage_spheres(lds, s.sph, 0, s.ns_padded);
+            staged = true;
+        }
+        __syncthreads();   // job[] read by all, spheres staged
+        if (kind == SCHED_JOB_A) {
+            trace_tile<true, LCMAX>(s, f, lds, cand, blk, single, lvl, tile, n, tc);
+            __syncthreads();   // every lane's child records are written ...
+            if (threadIdx.x == 0) {
+                __threadfence();   // ... and released to the device before the tile counts as done
+                const int tiles_a = (n + 255) >> 8;
+                if (atomicAdd(&sc->done_a[lvl], 1) + 1 == tiles_a) {
+                    __threadfence();
+                    __hip_atomic_store(&sc->open_level, lvl + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
-        }
-        if (active) {
-            tc.sph += ltc.sph;
-            tc.pl += ltc.pl;
-            tc.tri += ltc.tri;
-        }
-        if (active) tc.exact += ltc.exact;
-        if (SEC) {
-            const bool child = active && sec.prim != INT_MAX;
-            const f3 hit2 = add3(hit, scale3(sec_dir, sec.t));   // objects.cs:123,166,263
-            if (active) f.refl[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            const bool rv[1] = {child};
-            const int rp[1] = {child ? sec.prim : 0}, rparent[1] = {slot};
-            const f3 rh[1] = {hit2}, rd[1] = {sec_dir};
-            push_records<1>(f, s, level + 1, blk, rv, rp, rh, rd, rparent);
+        } else {
+            trace_tile<false, LCMAX>(s, f, lds, cand, blk, single, lvl, tile, n, tc);
         }
     }
-    const int ws = wave_sum(tc.sph), wp = wave_sum(tc.pl), wt = wave_sum(tc.tri);
-    if ((threadIdx.x & 63) == 0 && (ws | wp | wt) != 0) {
-        atomicAdd(&f.counters->sphere_tests, (unsigned long long)ws);
-        atomicAdd(&f.counters->plane_tests, (unsigned long long)wp);
-        atomicAdd(&f.counters->triangle_tests, (unsigned long long)wt);
-    }
-    const int we = wave_sum(tc.exact);
-    if ((threadIdx.x & 63) == 0 && we) atomicAdd(&f.counters->exact_candidates, (unsigned long long)we);
+    flush_test_counts(f, tc);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -882,6 +1010,26 @@ void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting,
         if (reflecting) hipLaunchKernelGGL((k_trace<true, 2>), g, b, 0, stream, s, f, level);
         else hipLaunchKernelGGL((k_trace<false, 2>), g, b, 0, stream, s, f, level);
     }
+}
+
+int rtk_trace_levels_resident_blocks(int nl, int num_cus)
+{
+    int per_cu = 0;
+    const hipError_t e = nl >= 4
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_levels<4>, 256, 0)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_levels<2>, 256, 0);
+    if (e != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    return per_cu * num_cus;
+}
+
+void rtk_trace_levels(const DevScene &s, const DevFrame &f, int grid_blocks, hipStream_t stream)
+{
+    const dim3 g(grid_blocks), b(256);
+    if (s.nl >= 4) hipLaunchKernelGGL(k_trace_levels<4>, g, b, 0, stream, s, f);
+    else hipLaunchKernelGGL(k_trace_levels<2>, g, b, 0, stream, s, f);
 }
 
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,

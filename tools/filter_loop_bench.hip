@@ -1,6 +1,7 @@
-// filter_loop_bench.hip — runs the generated primary filter loop (filter_asm.inc) alone on
-// never-passing data and reports cycles per VALU instruction, per occupancy.
+// filter_loop_bench.hip — runs generated filter loops (filter_asm.inc) alone on never-passing
+// data and reports cycles per VALU instruction, per occupancy.
 // Build: hipcc --offload-arch=gfx950 -O3 -I raytracer_amd/csrc tools/filter_loop_bench.hip -o tools/filter_loop_bench
+//        (-DFA_INC='"other.inc"' to time an experimental variant of the generator's output)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
@@ -12,19 +13,19 @@
 typedef float f4raw __attribute__((ext_vector_type(4)));
 #define CH 1024
 
-template <int PAD>
+// LOOP: 0 = primary loop (4 rays), 2 / 3 = trace loop with 2 / 3 rays.
+template <int LOOP>
 __global__ void __launch_bounds__(256) k(const float4 *sph, int reps, float *out)
 {
     __shared__ float4 lds[CH + FA_LDS_SLACK];
-    __shared__ float pad[PAD > 0 ? PAD : 1];   // extra LDS to cap the workgroups per CU
     __shared__ int cand[16 * 256];
     for (int i = threadIdx.x; i < CH + FA_LDS_SLACK; i += 256) lds[i] = sph[i];
-    if (PAD > 0) pad[threadIdx.x % PAD] = 0.f;
     __syncthreads();
     const float t = 1e-3f * threadIdx.x;
     const f4raw r0 = {0.f, 0.6f + t, 0.0f, 0.8f}, r1 = {0.f, 0.6f, t, 0.8f}, r2 = {0.f, 0.0f, 0.6f + t, 0.8f},
                 r3 = {0.f, t, 0.6f, 0.8f};
-    const float fm = 1e-5f;
+    const f4raw oq = {t, 1.0f, -t, 0.f};
+    const float fm = 1e-5f, k1 = 0.999996185302734375f;
     int hits = 0;
     for (int r = 0; r < reps; r++) {
         int i = 0;
@@ -34,52 +35,66 @@ __global__ void __launch_bounds__(256) k(const float4 *sph, int reps, float *out
         const unsigned qlim = q0 + 8 * 1024 + 1020;
         unsigned qaddr = q0;
         while (i < cnt) {
-            asm volatile(FA_PRIMARY4_ASM
-                         : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
-                         : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), FA_FM(fm), [cnt] "s"(cnt), [qlim] "s"(qlim)
-                         : FA_PRIMARY4_CLOBBERS);
+            if constexpr (LOOP == 0)
+                asm volatile(FA_PRIMARY4_ASM
+                             : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
+                             : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), FA_FM(fm), [cnt] "s"(cnt), [qlim] "s"(qlim)
+                             : FA_PRIMARY4_CLOBBERS);
+            if constexpr (LOOP == 2)
+                asm volatile(FA_TRACE2_ASM
+                             : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
+                             : FA_DN0(r0), FA_DN1(r1), FA_O(oq), FA_K1(k1), FA_FM(fm), [cnt] "s"(cnt), [qlim] "s"(qlim)
+                             : FA_TRACE2_CLOBBERS);
+            if constexpr (LOOP == 3)
+                asm volatile(FA_TRACE3_ASM
+                             : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
+                             : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_O(oq), FA_K1(k1), FA_FM(fm), [cnt] "s"(cnt),
+                               [qlim] "s"(qlim)
+                             : FA_TRACE3_CLOBBERS);
             hits += (int)(qaddr - q0);
             qaddr = q0;
         }
     }
-    if (PAD > 0) hits += (int)pad[0];
     out[blockIdx.x * 256 + threadIdx.x] = (float)hits;
 }
 
-template <int PAD>
-void run(const char *what, int blocks, const float4 *dsph, float *dout)
+template <int LOOP>
+void run(const char *what, int valu_per_trip, int blocks, int reps, const float4 *dsph, float *dout)
 {
-    const int reps = 20;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<PAD>, dim3(blocks), dim3(256), 0, 0, dsph, reps, dout);
+    hipLaunchKernelGGL(k<LOOP>, dim3(blocks), dim3(256), 0, 0, dsph, reps, dout);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL(k<PAD>, dim3(blocks), dim3(256), 0, 0, dsph, reps, dout);
+    hipLaunchKernelGGL(k<LOOP>, dim3(blocks), dim3(256), 0, 0, dsph, reps, dout);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    // 169 VALU per trip of 8 spheres (see filter_asm.inc)
-    const double instr_per_wave = (double)reps * (CH / 8) * 169.0;
+    const double instr_per_wave = (double)reps * (CH / 8) * valu_per_trip;
     const double waves_per_simd = blocks * 4.0 / 1024.0;
-    printf("%-34s blocks %5d  %8.3f ms  %.2f cycles per VALU instr per SIMD @2.4GHz\n", what, blocks, ms,
-           ms * 1e-3 * 2.4e9 / (instr_per_wave * waves_per_simd));
+    printf("%-10s blocks %5d reps %4d  %8.3f ms  %.2f cycles per VALU instr per SIMD @2.4GHz\n", what, blocks, reps,
+           ms, ms * 1e-3 * 2.4e9 / (instr_per_wave * waves_per_simd));
 }
 
 int main()
 {
     std::vector<float4> sph(CH + FA_LDS_SLACK);
+    // w = -inf: -c'' of the primary loop and r*r of the trace loops; neither ever passes.
     for (size_t i = 0; i < sph.size(); i++) sph[i] = make_float4(1.f + 0.001f * i, -2.f, 3.f, -INFINITY);
     float4 *dsph;
     float *dout;
     (void)hipMalloc(&dsph, sph.size() * sizeof(float4));
     (void)hipMalloc(&dout, 8192 * 256 * sizeof(float));
     (void)hipMemcpy(dsph, sph.data(), sph.size() * sizeof(float4), hipMemcpyHostToDevice);
-    run<0>("1 wave/SIMD  (256 blocks)", 256, dsph, dout);
-    run<0>("2 waves/SIMD (512 blocks)", 512, dsph, dout);
-    run<0>("4 waves/SIMD (1024 blocks)", 1024, dsph, dout);
-    run<0>("8 waves/SIMD requested (2048)", 2048, dsph, dout);
+    const int blocks[] = {512, 1024, 2048, 4096};
+    for (int b : blocks) {
+        for (int reps : {20, 80}) {
+            run<0>("primary4", FA_PRIMARY4_VALU, b, reps, dsph, dout);
+            run<2>("trace2", FA_TRACE2_VALU, b, reps, dsph, dout);
+            run<3>("trace3", FA_TRACE3_VALU, b, reps, dsph, dout);
+        }
+    }
     return 0;
 }

@@ -116,7 +116,12 @@ def filter_set(lines, K, trace, cur, ph=None):
     lines.append(f"v_and_b32 v{ALL}, v{ALL}, v{ACC(3, ph)}")
 
 
-def loads(lines, which, byte_offset):
+VARIANT = os.environ.get("FA_VARIANT", "")   # experiments only (tools/filter_loop_bench.hip)
+
+
+def loads(lines, which, byte_offset, first=False):
+    if "nolds" in VARIANT and not first:
+        return
     for u in range(NB):
         r = SET[which](u)
         lines.append(f"ds_read_b128 v[{r}:{r + 3}], %[addr] offset:{byte_offset + 16 * u}")
@@ -150,7 +155,9 @@ def append_block(L):
 
 def gen_loop(K, trace):
     L = []
-    loads(L, 0, 0)
+    loads(L, 0, 0, first=True)
+    if "nolds" in VARIANT:
+        loads(L, 1, 16 * NB, first=True)
     L.append(".LFA_LOOP%=:")
     L.append("s_waitcnt lgkmcnt(0)")
     loads(L, 1, 16 * NB)
@@ -198,6 +205,7 @@ def emit(name, K, trace):
     valu = sum(1 for l in probe if l.startswith("v_")) + 2
     out = [f"// {name}: {'trace' if trace else 'primary'} loop, {K} ray(s) per lane, {valu} VALU instructions per "
            f"trip of {2 * NB} spheres when nothing is queued"]
+    out.append(f"#define {name}_VALU {valu}")
     out.append(f"#define {name}_ASM \\")
     for l in lines:
         out.append(f'    "{l}\\n" \\')
@@ -209,7 +217,7 @@ def emit(name, K, trace):
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(here, "..", "raytracer_amd", "csrc", "filter_asm.inc")
+    path = os.environ.get("FA_OUT") or os.path.join(here, "..", "raytracer_amd", "csrc", "filter_asm.inc")
     out = ["// GENERATED by tools/gen_filter_asm.py - do not edit; edit the generator and re-run it.",
            "// Sphere-filter loops for gfx950 with a VGPR-bank-conflict-free register plan.",
            "// Register plan and calling convention: see the generator's module docstring.", ""]
