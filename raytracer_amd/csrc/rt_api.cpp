@@ -32,7 +32,6 @@ struct DeviceState {
     DevScene scene{};
     std::vector<void *> scene_allocs;
     float4 *sph_cam = nullptr;
-    float *sph_cam_c = nullptr;
     void *tex_mem[RT_MAX_TEXTURES] = {};
 
     // per-frame scratch
@@ -92,9 +91,7 @@ void free_scene(DeviceState &d)
     for (void *p : d.scene_allocs) (void)hipFree(p);
     d.scene_allocs.clear();
     if (d.sph_cam) (void)hipFree(d.sph_cam);
-    if (d.sph_cam_c) (void)hipFree(d.sph_cam_c);
     d.sph_cam = nullptr;
-    d.sph_cam_c = nullptr;
     const uchar4 *tex[RT_DEV_MAX_TEXTURES];
     int tw[RT_DEV_MAX_TEXTURES], th[RT_DEV_MAX_TEXTURES];
     memcpy(tex, d.scene.tex, sizeof tex);
@@ -138,11 +135,51 @@ int upload(rt_ctx *ctx, DeviceState &d, const std::vector<T> &host, const T **de
 }
 
 struct PackedScene {
-    std::vector<float4> sph, pl, tri, geo, mat, light_pos, light_col;
+    std::vector<float4> sph, sph_f, pl, tri, geo, mat, light_pos, light_col;
     std::vector<int> sph_orig, pl_orig, tri_orig, class_prefix;
     uint32_t textures_used = 0;
-    float sph_l1max = 0.f;
+    float sph_center[3] = {0.f, 0.f, 0.f};
+    float sph_l1max = 0.f, sph_sc = 0.f;
 };
+
+// The sphere filter's view of the spheres (rt_kernels.hip, "Sphere filter"): centres relative
+// to the middle of their bounding box, W = r*r - k1*|p'|^2 from double arithmetic on the
+// rounded p', and the two bounds the kernels' margins are built from (rounded up).  A sphere
+// with non-finite data can never be hit (every comparison of objects.cs:116-121 fails) and
+// gets the never-pass entry.
+void build_filter_array(PackedScene &out)
+{
+    const size_t n = out.sph.size();
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto usable = [](const float4 &s) {
+        return std::isfinite(s.x) && std::isfinite(s.y) && std::isfinite(s.z) && std::isfinite(s.w);
+    };
+    for (const float4 &s : out.sph) {
+        if (!usable(s)) continue;
+        const double c[3] = {s.x, s.y, s.z};
+        for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], c[k]), hi[k] = std::max(hi[k], c[k]);
+    }
+    for (int k = 0; k < 3; k++) out.sph_center[k] = lo[k] <= hi[k] ? (float)(0.5 * (lo[k] + hi[k])) : 0.f;
+    out.sph_f.assign(n, make_float4(0.f, 0.f, 0.f, -INFINITY));
+    double l1max = 0.0, p2max = 0.0, r2max = 0.0;
+    for (size_t i = 0; i < n; i++) {
+        const float4 &s = out.sph[i];
+        if (!usable(s)) continue;
+        const float px = (float)((double)s.x - (double)out.sph_center[0]);
+        const float py = (float)((double)s.y - (double)out.sph_center[1]);
+        const float pz = (float)((double)s.z - (double)out.sph_center[2]);
+        const double p2 = (double)px * px + (double)py * py + (double)pz * pz;
+        const float w = (float)((double)s.w - (double)RT_FILTER_K1 * p2);
+        if (!std::isfinite(w)) continue;
+        out.sph_f[i] = make_float4(px, py, pz, w);
+        l1max = std::max(l1max, std::fabs((double)px) + std::fabs((double)py) + std::fabs((double)pz));
+        p2max = std::max(p2max, p2);
+        r2max = std::max(r2max, (double)s.w);
+    }
+    const double up = 1.0 + 1e-6;   // far above the single rounding to float
+    out.sph_l1max = (float)(l1max * up);
+    out.sph_sc = (float)((2.0 * p2max + r2max) * up);
+}
 
 int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
 {
@@ -165,7 +202,6 @@ int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
             const float r = s->prim_radius[i];
             out.sph.push_back(make_float4(p[0], p[1], p[2], r * r));  // objects.cs:114 radius*radius
             out.sph_orig.push_back(i);
-            out.sph_l1max = std::max(out.sph_l1max, std::fabs(p[0]) + std::fabs(p[1]) + std::fabs(p[2]));
             g = make_float4(p[0], p[1], p[2], 0.f);
             cs++;
         } else if (type == RT_PRIM_PLANE) {
@@ -207,6 +243,7 @@ int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
         out.sph.push_back(make_float4(0.f, 0.f, 0.f, -INFINITY));
         out.sph_orig.push_back(INT32_MAX);
     }
+    build_filter_array(out);
     out.class_prefix[3 * (size_t)n + 0] = cs;
     out.class_prefix[3 * (size_t)n + 1] = cp;
     out.class_prefix[3 * (size_t)n + 2] = ct;
@@ -234,6 +271,7 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     sc.nprims = n;
     int rc;
     if ((rc = upload(ctx, d, ps.sph, &sc.sph)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.sph_f, &sc.sph_f)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.sph_orig, &sc.sph_orig)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.pl, &sc.pl)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.pl_orig, &sc.pl_orig)) != RT_OK) return rc;
@@ -245,10 +283,10 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     if ((rc = upload(ctx, d, ps.light_col, &sc.light_col)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.class_prefix, &sc.class_prefix)) != RT_OK) return rc;
     HIP_TRY(ctx, hipMalloc((void **)&d.sph_cam, std::max<size_t>(ps.sph.size() * sizeof(float4), 16)));
-    HIP_TRY(ctx, hipMalloc((void **)&d.sph_cam_c, std::max<size_t>(ps.sph.size() * sizeof(float), 16)));
     sc.sph_cam = d.sph_cam;
-    sc.sph_cam_c = d.sph_cam_c;
+    for (int k = 0; k < 3; k++) sc.sph_center[k] = ps.sph_center[k];
     sc.sph_l1max = ps.sph_l1max;
+    sc.sph_sc = ps.sph_sc;
     return RT_OK;
 }
 
@@ -376,7 +414,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     d.timed = ctx->profiling && stream == d.stream;
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
     const int blocks = std::max(1, std::min((P + 255) / 256, d.num_cus * 8));
-    rtk_setup_camera(d.scene, dc, d.sph_cam, d.sph_cam_c, stream);
+    rtk_setup_camera(d.scene, dc, d.sph_cam, stream);
     rtk_primary(d.scene, dc, f, dev_pixels, blocks, stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[1], stream));
     // RT_HIP_LEVEL_KERNELS=1 (profiling aid): one launch per queue per level on this stream,

@@ -4,17 +4,18 @@
 // Scene in HBM (structure of arrays, one array per primitive class, each in the
 // host's insertion order; *_orig maps back to the host's primitive index, which is
 // what decides ties in closest-hit, MyApplication.cs:361):
-//   sph      float4 {cx, cy, cz, r*r}        one per sphere
-//   sph_cam  float4 {ox-cx, oy-cy, oz-cz, c''} per frame for the camera origin o; c'' is
-//                                            the sphere filter's constant (rt_kernels.hip)
-//   sph_cam_c float  c = |o-p|^2 - r*r       per frame, exact (objects.cs:113-114)
+//   sph      float4 {cx, cy, cz, r*r}        one per sphere, what the exact evaluation reads
+//   sph_f    float4 {p'x, p'y, p'z, W}       the sphere filter's view of the same spheres:
+//                                            p' = centre - sph_center, W = r*r - k1*|p'|^2
+//                                            (rt_kernels.hip, "Sphere filter")
+//   sph_cam  float4 {p'x, p'y, p'z, -c''}    per frame: the filter's term for the camera origin
 //   pl       float4 {nx, ny, nz, d}          one per plane
 //   tri      float4 x3 {v0}, {e1}, {e2}      e1 = v1-v0, e2 = v2-v0 (objects.cs:238-239)
 //   geo      float4 per host primitive: sphere centre or plane/triangle normal
 //   mat      float4 x3 per host primitive: {diffuse.rgb, specular},
 //            {glossy.rgb, flags}, {ambient.rgb, -}
 //   light_pos / light_col  float4 per light
-// The sphere arrays are staged in LDS by each workgroup and read from there into VGPRs
+// The filter arrays are staged in LDS by each workgroup and read from there into VGPRs
 // (one ds_read_b128 per sphere per wave, all lanes the same address); the small arrays
 // (planes, triangles, lights) are wave-uniform and read through the scalar cache.
 #pragma once
@@ -30,17 +31,21 @@
 #define RT_MF_TEX_SHIFT   4        // texture slot + 1 in bits 4..7 (0 = none)
 #define RT_MF_TEX_MASK    0xF0
 
-// sph, sph_cam and sph_orig are padded to a multiple of RT_SPH_PAD entries; the padding
-// is {0, 0, 0, -inf}, which makes c = +inf so that no ray passes the sphere filter.
+// sph, sph_f, sph_cam and sph_orig are padded to a multiple of RT_SPH_PAD entries; the
+// padding is {0, 0, 0, -inf}, which no ray passes in the sphere filter.
 #define RT_SPH_PAD 8
+// k1 = 1 - 2^-18, the filter's relative margin (shared by the host's W and the kernels).
+#define RT_FILTER_K1 0.999996185302734375f
 
 struct DevScene {
     int ns, np, nt, nl, nprims;
     int ns_padded;
-    float sph_l1max;          // max over spheres of |cx| + |cy| + |cz| (bound used by the filter)
+    float sph_center[3];      // the filter's coordinate origin (centre of the spheres' bounding box)
+    float sph_l1max;          // >= max over spheres of |p'|_1
+    float sph_sc;             // >= 2 max |p'|^2 + max r*r
     const float4 *sph;
-    const float4 *sph_cam;    // per frame: {o-p, filter constant} for the camera origin
-    const float *sph_cam_c;   // per frame: exact c = |o-p|^2 - r*r for the camera origin
+    const float4 *sph_f;
+    const float4 *sph_cam;    // per frame: {p', filter term} for the camera origin
     const int *sph_orig;
     const float4 *pl;
     const int *pl_orig;
@@ -114,8 +119,7 @@ struct DevFrame {
 };
 
 // Launch wrappers (rt_kernels.hip).  All enqueue on `stream` and return at once.
-void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, float *sph_cam_c,
-                      hipStream_t stream);
+void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, hipStream_t stream);
 void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels,
                  int grid_blocks, hipStream_t stream);
 // reflecting: the level's records that need a reflection trace (queue A) or the others (B).

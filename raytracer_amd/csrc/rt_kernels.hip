@@ -9,7 +9,7 @@
 // could accept, so it cannot change a result.
 //
 // Pipeline per frame (one HIP stream, in order):
-//   setup_camera   per sphere: o-p and the filter constant for the camera origin
+//   setup_camera   per sphere: the filter's per-sphere term for the camera origin
 //   primary        per pixel: ray direction, closest hit -> level-0 hit record
 //   trace_level k  per hit record: its light rays (any-hit) and, if the surface is
 //                  specular and k < max_depth, its reflection ray (closest hit) walk the
@@ -33,9 +33,9 @@
 #define RT_EPS 0.0001f
 #define RT_FLT_MAX 3.40282347e+38f
 // Margins of the sphere filter (derivation: "Sphere filter" below); u = 2^-24.
-#define FILTER_K1 0.999996185302734375f      // 1 - 2^-18 = 1 - 64u
+#define FILTER_K1 RT_FILTER_K1               // 1 - 2^-18 = 1 - 64u
 #define FILTER_FM_SCALE 9.5367431640625e-07f // 2^-20   = 16u
-#define SPH_BATCH 4   // RT_SPH_PAD = 2 * SPH_BATCH
+#define FILTER_E_SCALE 9.5367431640625e-07f  // 2^-20   = 16u
 
 // ---------------------------------------------------------------------------------------
 // OpenTK.Mathematics Vector3 operators, restated (Dot / Cross / Length / Normalized).
@@ -230,61 +230,125 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
 }
 
 // ---------------------------------------------------------------------------------------
-// setup_camera: per sphere, the terms of Sphere.Intersect that depend only on the ray
-// origin (objects.cs:113-114).  Every primary ray starts at camera.position, so they
-// are computed once per frame instead of once per pixel; same operations, same bits.
-// sph_cam[i] = {o-p, -c''} (c'' = the filter's constant), sph_cam_c[i] = exact c.
-// ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam, float4 *sph_cam, float *sph_cam_c)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= s.ns_padded) return;
-    const float4 sp = s.sph[i];
-    const f3 op = sub3(mk3(cam.pos[0], cam.pos[1], cam.pos[2]), xyz(sp));
-    // Exact c of objects.cs:114 for the exact pass (padding: |o|^2 - (-inf) = +inf) ...
-    sph_cam_c[i] = dot3(op, op) - sp.w;
-    // ... and the filter's -c'' (see "Sphere filter" below; padding: -inf, never passes).
-    const float q = __builtin_fmaf(op.z, op.z, __builtin_fmaf(op.y, op.y, op.x * op.x));
-    sph_cam[i] = make_float4(op.x, op.y, op.z, -__builtin_fmaf(q, FILTER_K1, -sp.w));
-}
-
-// ---------------------------------------------------------------------------------------
 // Sphere filter.
 //
 // For a ray (o, d) and a sphere (p, r) the reference computes, in FP32 without contraction
 // (objects.cs:112-121):  a = d.d,  x = d.(o-p),  c = (o-p).(o-p) - r*r,  disc = 4(x*x - a*c),
-// and only a pair with disc >= 0 and x < 0 can produce t > epsilon.  The filter evaluates
-// the same quantities with FMAs (3 + 1 instead of 5 + 3 operations per ray) and makes up
-// for the different rounding with two margins, u = 2^-24:
-//   x' = fma(-dz, opz, fma(-dy, opy, fma(-dx, opx, fm))),  fm = 16u * B1,
-//        B1 = |o|_1 + max_j |p_j|_1 >= |o - p|:  both evaluations of d.(o-p) are within
-//        3u|d||o-p| of the true value, so  x_ref < 0  implies  x' >= |x_ref| >= 0;
-//   c'' = fma(q, 1 - 64u, -r*r),  q = fma-evaluated |o-p|^2:  disc_ref >= 0 implies
-//        x_ref^2 >= q - r*r - 17u*q (a >= 1 - 6u for a normalised d, three roundings in c,
-//        one in each product), and c'' <= q - r*r - 62u*q, so  x'^2 - c'' >= 0.
-// A pair passes when  v = fma(x', x', -c'')  and  x'  both have a clear sign bit, i.e. when
-// (bits(v) | bits(x')) >= 0 as an integer.  Per sphere the verdicts of all rays are ANDed;
-// a sphere whose combined word is >= 0 in any lane goes to the exact code, which repeats
-// the reference's evaluation literally (sphere_maybe / sphere_root).  NaNs and infinities
-// can only add spurious passes, never remove one; padding entries (r*r = -inf) give
-// c'' = +inf, v = -inf and never pass.
+// and only a pair with disc >= 0 and x < 0 can produce t > epsilon.  Call the computed values
+// x_ref, c_ref and the exact ones (real arithmetic on the same FP32 inputs) X, Q = |o-p|^2.
+// The filter works in coordinates relative to a per-scene centre z (DevScene::sph_center):
+//   o' = fl(o - z),  p' = fl(p - z)  (p' rounded once on the host),  w = o' - p' exactly,
+// so o - p = w + eps with |eps_i| <= u(|o'_i| + |p'_i|), u = 2^-24.  With the bounds
+//   B1 = |o'|_1 + max_j |p'_j|_1   and   B2 = |o'|_2 + |p'|_2 <= B1
+// it evaluates, all in FMAs:
+//   per ray      e  = fm - d.o'                     fm = 16u * B1
+//   per pair     x' = e + d.p'                      = fm - d.w up to 6 roundings <= 6.1u*B1
+//   per sphere   -c'' = W + B.p' - C0               W = fl(r*r - k1*|p'|^2) (host, from double),
+//                                                   B = fl(2*k1*o'),  C0 = fl(k1*|o'|^2) - E,
+//                                                   k1 = 1 - 64u,  E = 16u * (2|o'|^2 + S),
+//                                                   S >= 2 max|p'|^2 + max r*r  (DevScene::sph_sc)
+//                i.e. c'' = k1*|w|^2 - r*r - E up to roundings <= 9.1u(r*r + B2^2) + 7u*E
+//   verdict      v = fma(x', |x'|, -c'');  the pair passes when v's sign bit is clear.
+// No accepted pair is lost:
+//   (1) x_ref < 0  =>  x' >= |x_ref|.  x_ref = X + eta with |eta| <= 4.1u|o-p| <= 4.1u*B1
+//       (one rounding per component of o-p, three products, two sums); X = d.w + d.eps with
+//       |d.eps| <= 1.1u*B1.  Hence x' >= fm - X - 7.2u*B1 >= -X - eta = |x_ref| because
+//       fm = 16u*B1 >= 11.3u*B1.
+//   (2) disc_ref >= 0  =>  x_ref^2 >= T := Q(1 - 14.2u) - r*r.  For c_ref > 0: fl(x_ref^2) >=
+//       fl(a_ref*c_ref) with a_ref >= 1 - 6u (d is a normalised vector), c_ref >=
+//       (q_ref - r*r)(1 - u), q_ref >= Q(1 - 5.1u); for c_ref <= 0, T <= 0 anyway.
+//   (3) c'' <= T.  Q >= |w|^2 - 2u*B2^2, so T >= |w|^2(1 - 14.2u) - 2u*B2^2 - r*r, while the
+//       computed c'' <= k1|w|^2 - r*r - E(1 - 7u) + 9.1u(r*r + B2^2); the difference is
+//       <= -49.8u|w|^2 - E(1 - 7u) + 11.1u*B2^2 + 9.1u*r*r <= 0 because B2^2 <= 2|o'|^2 +
+//       2 max|p'|^2 and therefore E >= 16u(1 - 5u)(B2^2 + r*r).
+//   With (1)-(3): x'|x'| = x'^2 >= x_ref^2 >= T >= c'', so v >= 0 and its sign bit is clear.
+// What the margins cost: the sphere looks larger by E in r*r, a few 1e-5 for scene extents
+// of a few units.  A sphere with non-finite data gets W = -inf (v = -inf, never passes); the
+// reference never accepts such a sphere either.  The argument assumes |o'|^2, |p'|^2 do not
+// overflow FP32; where they do, the reference's own c is infinite or NaN and it accepts nothing.
+// Per sphere the words v of all rays are ANDed; a sphere whose combined word is >= 0 (as an
+// integer) in a lane goes to that lane's exact code, which repeats the reference's
+// evaluation literally (sphere_maybe / sphere_root).
+// ---------------------------------------------------------------------------------------
+struct FilterOrigin {
+    f4raw lane;   // (Bx, By, Bz, C0): the filter loops' per-origin operand
+    f3 oc;        // o' = o - centre
+    float fm;     // front margin
+};
+
+__device__ __forceinline__ FilterOrigin filter_origin(const DevScene &s, f3 o)
+{
+    FilterOrigin fo;
+    fo.oc = mk3(o.x - s.sph_center[0], o.y - s.sph_center[1], o.z - s.sph_center[2]);
+    fo.fm = FILTER_FM_SCALE * (((fabsf(fo.oc.x) + fabsf(fo.oc.y)) + fabsf(fo.oc.z)) + s.sph_l1max);
+    const float oo = __builtin_fmaf(fo.oc.z, fo.oc.z, __builtin_fmaf(fo.oc.y, fo.oc.y, fo.oc.x * fo.oc.x));
+    const float e = FILTER_E_SCALE * __builtin_fmaf(2.0f, oo, s.sph_sc);
+    const float k2 = 2.0f * FILTER_K1;
+    fo.lane = f4raw{k2 * fo.oc.x, k2 * fo.oc.y, k2 * fo.oc.z, (FILTER_K1 * oo) - e};
+    return fo;
+}
+
+// (e, dx, dy, dz): one ray's operand of the filter loops.
+__device__ __forceinline__ f4raw filter_ray(const FilterOrigin &fo, f3 d)
+{
+    const float e = __builtin_fmaf(-d.z, fo.oc.z, __builtin_fmaf(-d.y, fo.oc.y, __builtin_fmaf(-d.x, fo.oc.x, fo.fm)));
+    return f4raw{e, d.x, d.y, d.z};
+}
+
+// ---------------------------------------------------------------------------------------
+// setup_camera: every primary ray starts at camera.position, so the filter's per-sphere
+// term -c'' for that origin is computed once per frame: sph_cam[i] = {p', -c''}.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam, float4 *sph_cam)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.ns_padded) return;
+    const FilterOrigin fo = filter_origin(s, mk3(cam.pos[0], cam.pos[1], cam.pos[2]));
+    const float4 pf = s.sph_f[i];
+    const float chain = __builtin_fmaf(fo.lane.x, pf.x, __builtin_fmaf(fo.lane.y, pf.y, __builtin_fmaf(fo.lane.z, pf.z, pf.w)));
+    sph_cam[i] = make_float4(pf.x, pf.y, pf.z, chain - fo.lane.w);   // padding: -inf, never passes
+}
+
 // ---------------------------------------------------------------------------------------
 // The filter loops themselves are gfx950 assembly with a fixed, VGPR-bank-conflict-free
 // register plan (filter_asm.inc, generated by tools/gen_filter_asm.py): hipcc's register
 // allocation ignores banks, and a three-source instruction with two sources in one bank
-// issues at half rate.  A loop walks the spheres staged in LDS, four per batch; lanes whose
-// rays could hit a sphere of the batch queue its index in LDS and the loop goes on.  The
+// issues at half rate.  A loop walks the spheres staged in LDS, eight per trip; lanes whose
+// rays could hit a sphere of the trip queue one word in LDS and the loop goes on.  The
 // exact evaluation then runs here in C++ over each lane's (short) queue, in index order.
 
-// Spheres staged per workgroup: SPH_CHUNK entries of {cx, cy, cz, r*r} (or, for the primary
-// kernel, {ox-cx, oy-cy, oz-cz, -c''}) plus FA_LDS_SLACK never-pass entries for the loops'
-// read-ahead.
+// Spheres staged per workgroup: SPH_CHUNK filter entries {p', W} (or, for the primary kernel,
+// {p', -c''}) plus FA_LDS_SLACK never-pass entries for the loops' read-ahead.
 #define SPH_CHUNK 1024
 #define SPH_LDS_ENTRIES (SPH_CHUNK + FA_LDS_SLACK)
-// Candidate queues: QUEUE_SLOTS sphere indices per thread, slot-major (slot s of thread t at
-// int index 256*s + t).  A loop returns early when a queue could not take another batch.
+// Candidate queues: QUEUE_SLOTS words per thread, slot-major (slot s of thread t at int index
+// 256*s + t).  A word names a trip of FA_TRIP spheres and which of them the lane's rays could
+// hit: (first index << 8) | reject mask, sphere m of the trip = bit 7-m, 0 = could hit.  A
+// loop returns early when some thread's queue is full.
 #define QUEUE_SLOTS 16
 #define QUEUE_INTS (QUEUE_SLOTS * 256)
+
+// Walks a thread's queued words in index order: next() returns the next sphere index (local to
+// the staged chunk) the lane has to evaluate exactly, or -1 when its queue is exhausted.
+struct CandidateWalk {
+    const int *cand;
+    int nq, j, trip;
+    unsigned pass;
+    __device__ __forceinline__ CandidateWalk(const int *cand_, int nq_) : cand(cand_), nq(nq_), j(0), trip(0), pass(0u) {}
+    __device__ __forceinline__ int next()
+    {
+        if (pass == 0u) {
+            if (j >= nq) return -1;
+            const unsigned w = (unsigned)cand[j * 256 + threadIdx.x];
+            j++;
+            trip = (int)(w >> 8);
+            pass = (w & 0xffu) ^ 0xffu;   // never 0: only lanes with a candidate queue a word
+        }
+        const int b = 31 - __clz((int)pass);   // highest bit = lowest sphere index first
+        pass &= ~(1u << b);
+        return trip + 7 - b;
+    }
+};
 
 __device__ __forceinline__ void stage_spheres(float4 *lds, const float4 *src, int base, int count)
 {
@@ -292,13 +356,12 @@ __device__ __forceinline__ void stage_spheres(float4 *lds, const float4 *src, in
     if (threadIdx.x < FA_LDS_SLACK) lds[count + threadIdx.x] = make_float4(0.f, 0.f, 0.f, -INFINITY);
 }
 
+
 // Byte offset of an LDS object inside the workgroup's LDS allocation (what ds_read takes).
 __device__ __forceinline__ unsigned lds_offset(const void *p)
 {
     return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char *)p;
 }
-
-__device__ __forceinline__ f4raw ray_operand(f3 d) { return f4raw{0.0f, d.x, d.y, d.z}; }
 
 // GetRayDirection's per-pixel part, MyApplication.cs:438-449.
 __device__ __forceinline__ f3 primary_direction(const DevCamera &cam, int px, int py)
@@ -334,7 +397,7 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
     const int nsp = s.ns_padded;
     const bool single = nsp <= SPH_CHUNK;
     const f3 o = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
-    const float fm = FILTER_FM_SCALE * (((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) + s.sph_l1max);
+    const FilterOrigin fo = filter_origin(s, o);
     if (single) {
         stage_spheres(lds, s.sph_cam, 0, nsp);
         __syncthreads();
@@ -368,30 +431,29 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
                 stage_spheres(lds, s.sph_cam, base, cnt);
                 __syncthreads();
             }
-            const f4raw r0 = ray_operand(d[0]), r1 = ray_operand(d[1]), r2 = ray_operand(d[2]),
-                        r3 = ray_operand(d[3]);
+            const f4raw r0 = filter_ray(fo, d[0]), r1 = filter_ray(fo, d[1]), r2 = filter_ray(fo, d[2]),
+                        r3 = filter_ray(fo, d[3]);
             const unsigned q0 = lds_offset(cand) + 4u * threadIdx.x;
-            const unsigned qlim = lds_offset(cand) + (QUEUE_SLOTS - FA_TRIP) * FA_QUEUE_STRIDE + 4u * 255u;
+            const unsigned qlim = lds_offset(cand) + QUEUE_SLOTS * FA_QUEUE_STRIDE;
             unsigned qaddr = q0, addr = lds_offset(lds);
             int i = 0;
             while (true) {
                 if (i < cnt)
                     asm volatile(FA_PRIMARY4_ASM
                                  : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
-                                 : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), FA_FM(fm), [cnt] "s"(cnt),
-                                   [qlim] "s"(qlim)
+                                 : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), [cnt] "s"(cnt), [qlim] "s"(qlim)
                                  : FA_PRIMARY4_CLOBBERS);
-                // Exact evaluation of the queued spheres: objects.cs:112-121 literally; c for the
-                // camera origin as setup_camera stored it.  Queue order = index order, so the
-                // strict `<` keeps the first of equal distances.
-                const int nq = (int)((qaddr - q0) / FA_QUEUE_STRIDE);
-                candidates += nq;
-                for (int j = 0; __ballot(j < nq) != 0ull; j++) {
-                    if (j < nq) {
-                        const int li = cand[j * 256 + threadIdx.x];
-                        const float4 sp = lds[li];
-                        const f3 op = xyz(sp);
-                        const float c = s.sph_cam_c[base + li];
+                // Exact evaluation of the queued spheres: objects.cs:112-121 literally.  Queue
+                // order = index order, so the strict `<` keeps the first of equal distances.
+                CandidateWalk walk(cand, (int)((qaddr - q0) / FA_QUEUE_STRIDE));
+                for (;;) {
+                    const int li = walk.next();
+                    if (__ballot(li >= 0) == 0ull) break;
+                    if (li >= 0) {
+                        candidates++;
+                        const float4 sp = s.sph[base + li];
+                        const f3 op = sub3(o, xyz(sp));
+                        const float c = dot3(op, op) - sp.w;
 #pragma unroll
                         for (int k = 0; k < PRIM_PX; k++) {
                             const float xx = dot3(d[k], op);
@@ -446,9 +508,9 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
 // ---------------------------------------------------------------------------------------
 // trace_level: for each hit record, IsInShadow towards every light (objects.cs:51-60)
 // and, for specular surfaces below the depth bound, scene.Intersect along the mirror
-// direction (objects.cs:82-83).  All of a record's rays start at its hit point, so o-p and
-// the filter constant are formed once per sphere and shared by the record's NR rays: a
-// sphere costs 7 + 6*NR full-rate instructions per lane.
+// direction (objects.cs:82-83).  All of a record's rays start at its hit point, so
+// the filter's per-sphere term is formed once per sphere and shared by the record's NR rays:
+// a sphere costs 4 + 4*NR full-rate instructions per lane plus one per two or three rays.
 // ---------------------------------------------------------------------------------------
 template <int LC, bool SEC>
 struct Rays {
@@ -468,13 +530,11 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, int *ca
     constexpr int NR = LC + (SEC ? 1 : 0);
     static_assert(NR >= 1 && NR <= 5, "one filter loop per ray count 1..5");
     // Ray operands of the filter loop: light rays first, the reflection ray last.
+    const FilterOrigin fo = filter_origin(s, o);
     f4raw rq[5];
 #pragma unroll
-    for (int l = 0; l < LC; l++) rq[l] = ray_operand(r.sh_d[l]);
-    if (SEC) rq[LC] = ray_operand(r.sec_d);
-    const f4raw oq = f4raw{o.x, o.y, o.z, 0.0f};
-    const float fm = FILTER_FM_SCALE * (((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) + s.sph_l1max);
-    const float k1 = FILTER_K1;
+    for (int l = 0; l < LC; l++) rq[l] = filter_ray(fo, r.sh_d[l]);
+    if (SEC) rq[LC] = filter_ray(fo, r.sec_d);
 
     float best_t = RT_FLT_MAX;
     int best_i = -1;
@@ -483,18 +543,18 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, int *ca
         const int cnt = min(SPH_CHUNK, nsp - base);
         if (!single) {
             __syncthreads();
-            stage_spheres(lds, s.sph, base, cnt);
+            stage_spheres(lds, s.sph_f, base, cnt);
             __syncthreads();
         }
         const unsigned q0 = lds_offset(cand) + 4u * threadIdx.x;
-        const unsigned qlim = lds_offset(cand) + (QUEUE_SLOTS - FA_TRIP) * FA_QUEUE_STRIDE + 4u * 255u;
+        const unsigned qlim = lds_offset(cand) + QUEUE_SLOTS * FA_QUEUE_STRIDE;
         unsigned qaddr = q0, addr = lds_offset(lds);
         int i = 0;
         while (true) {
 #define FA_RUN(NAME, ...)                                                                 \
     asm volatile(NAME##_ASM                                                               \
                  : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)                    \
-                 : __VA_ARGS__, FA_O(oq), FA_K1(k1), FA_FM(fm), [cnt] "s"(cnt), [qlim] "s"(qlim) \
+                 : __VA_ARGS__, FA_LANE(fo.lane), [cnt] "s"(cnt), [qlim] "s"(qlim)           \
                  : NAME##_CLOBBERS)
             if (i < cnt) {
                 if constexpr (NR == 1) FA_RUN(FA_TRACE1, FA_DN0(rq[0]));
@@ -508,12 +568,13 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, int *ca
 #undef FA_RUN
             // Exact evaluation of the queued spheres, in index order (Sphere.Intersect
             // objects.cs:112-121, literally).
-            const int nq = (int)((qaddr - q0) / FA_QUEUE_STRIDE);
-            candidates += nq;
-            for (int j = 0; __ballot(j < nq) != 0ull; j++) {
-                if (j < nq) {
-                    const int li = cand[j * 256 + threadIdx.x];
-                    const float4 sp = lds[li];
+            CandidateWalk walk(cand, (int)((qaddr - q0) / FA_QUEUE_STRIDE));
+            for (;;) {
+                const int li = walk.next();
+                if (__ballot(li >= 0) == 0ull) break;
+                if (li >= 0) {
+                    candidates++;
+                    const float4 sp = s.sph[base + li];
                     const f3 op = sub3(o, xyz(sp));
                     const float c = dot3(op, op) - sp.w;
                     float t;
@@ -724,7 +785,7 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
     const int ntiles = (n + 255) >> 8;
     const bool single = s.ns_padded <= SPH_CHUNK;
     if (single && (int)blockIdx.x < ntiles) {
-        stage_spheres(lds, s.sph, 0, s.ns_padded);
+        stage_spheres(lds, s.sph_f, 0, s.ns_padded);
         __syncthreads();
     }
     TestCount tc = {0, 0, 0, 0};
@@ -765,7 +826,8 @@ __device__ __forceinline__ int sched_load(const int *p)
 }
 
 template <int LCMAX>
-__global__ void __launch_bounds__(256) k_trace_levels(DevScene s, DevFrame f)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+k_trace_levels(DevScene s, DevFrame f)
 {
     __shared__ float4 lds[SPH_LDS_ENTRIES];
     __shared__ int cand[QUEUE_INTS];
@@ -825,7 +887,7 @@ __global__ void __launch_bounds__(256) k_trace_levels(DevScene s, DevFrame f)
         const int kind = job[0], lvl = job[1], tile = job[2], n = job[3];
         if (kind == SCHED_JOB_EXIT) break;
         if (single && !staged) {
-            stage_spheres(lds, s.sph, 0, s.ns_padded);
+            stage_spheres(lds, s.sph_f, 0, s.ns_padded);
             staged = true;
         }
         __syncthreads();   // job[] read by all, spheres staged
@@ -982,12 +1044,10 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
 // ---------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------
-void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, float *sph_cam_c,
-                      hipStream_t stream)
+void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, hipStream_t stream)
 {
     if (s.ns_padded <= 0) return;
-    hipLaunchKernelGGL(k_setup_camera, dim3((s.ns_padded + 255) / 256), dim3(256), 0, stream, s, cam, sph_cam,
-                       sph_cam_c);
+    hipLaunchKernelGGL(k_setup_camera, dim3((s.ns_padded + 255) / 256), dim3(256), 0, stream, s, cam, sph_cam);
 }
 
 void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels, int grid_blocks,

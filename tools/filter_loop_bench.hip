@@ -22,10 +22,9 @@ __global__ void __launch_bounds__(256) k(const float4 *sph, int reps, float *out
     for (int i = threadIdx.x; i < CH + FA_LDS_SLACK; i += 256) lds[i] = sph[i];
     __syncthreads();
     const float t = 1e-3f * threadIdx.x;
-    const f4raw r0 = {0.f, 0.6f + t, 0.0f, 0.8f}, r1 = {0.f, 0.6f, t, 0.8f}, r2 = {0.f, 0.0f, 0.6f + t, 0.8f},
-                r3 = {0.f, t, 0.6f, 0.8f};
-    const f4raw oq = {t, 1.0f, -t, 0.f};
-    const float fm = 1e-5f, k1 = 0.999996185302734375f;
+    const f4raw r0 = {0.1f, 0.6f + t, 0.0f, 0.8f}, r1 = {0.2f, 0.6f, t, 0.8f}, r2 = {0.3f, 0.0f, 0.6f + t, 0.8f},
+                r3 = {0.4f, t, 0.6f, 0.8f};
+    const f4raw lane = {t, 1.0f, -t, 0.5f};
     int hits = 0;
     for (int r = 0; r < reps; r++) {
         int i = 0;
@@ -38,18 +37,17 @@ __global__ void __launch_bounds__(256) k(const float4 *sph, int reps, float *out
             if constexpr (LOOP == 0)
                 asm volatile(FA_PRIMARY4_ASM
                              : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
-                             : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), FA_FM(fm), [cnt] "s"(cnt), [qlim] "s"(qlim)
+                             : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), [cnt] "s"(cnt), [qlim] "s"(qlim)
                              : FA_PRIMARY4_CLOBBERS);
             if constexpr (LOOP == 2)
                 asm volatile(FA_TRACE2_ASM
                              : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
-                             : FA_DN0(r0), FA_DN1(r1), FA_O(oq), FA_K1(k1), FA_FM(fm), [cnt] "s"(cnt), [qlim] "s"(qlim)
+                             : FA_DN0(r0), FA_DN1(r1), FA_LANE(lane), [cnt] "s"(cnt), [qlim] "s"(qlim)
                              : FA_TRACE2_CLOBBERS);
             if constexpr (LOOP == 3)
                 asm volatile(FA_TRACE3_ASM
                              : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
-                             : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_O(oq), FA_K1(k1), FA_FM(fm), [cnt] "s"(cnt),
-                               [qlim] "s"(qlim)
+                             : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_LANE(lane), [cnt] "s"(cnt), [qlim] "s"(qlim)
                              : FA_TRACE3_CLOBBERS);
             hits += (int)(qaddr - q0);
             qaddr = q0;
@@ -81,16 +79,16 @@ void run(const char *what, int valu_per_trip, int blocks, int reps, const float4
 int main()
 {
     std::vector<float4> sph(CH + FA_LDS_SLACK);
-    // w = -inf: -c'' of the primary loop and r*r of the trace loops; neither ever passes.
+    // w = -inf: neither loop ever passes such an entry.
     for (size_t i = 0; i < sph.size(); i++) sph[i] = make_float4(1.f + 0.001f * i, -2.f, 3.f, -INFINITY);
     float4 *dsph;
     float *dout;
     (void)hipMalloc(&dsph, sph.size() * sizeof(float4));
     (void)hipMalloc(&dout, 8192 * 256 * sizeof(float));
     (void)hipMemcpy(dsph, sph.data(), sph.size() * sizeof(float4), hipMemcpyHostToDevice);
-    const int blocks[] = {512, 1024, 2048, 4096};
+    const int blocks[] = {512, 768, 1024, 2048, 3072, 4096};
     for (int b : blocks) {
-        for (int reps : {20, 80}) {
+        for (int reps : {80}) {
             run<0>("primary4", FA_PRIMARY4_VALU, b, reps, dsph, dout);
             run<2>("trace2", FA_TRACE2_VALU, b, reps, dsph, dout);
             run<3>("trace3", FA_TRACE3_VALU, b, reps, dsph, dout);
