@@ -110,6 +110,10 @@ LIB_NAME = "librt_hip.so"
 
 
 def library_path() -> str:
+    """The in-tree library; RT_HIP_LIBRARY names another build of it (A/B timing of variants)."""
+    override = os.environ.get("RT_HIP_LIBRARY")
+    if override:
+        return os.path.abspath(override)
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
 
 

@@ -31,7 +31,7 @@ struct DeviceState {
     // scene
     DevScene scene{};
     std::vector<void *> scene_allocs;
-    float4 *sph_cam = nullptr;
+    float4 *sph_cam = nullptr, *grp_cam = nullptr;
     void *tex_mem[RT_MAX_TEXTURES] = {};
 
     // per-frame scratch
@@ -91,7 +91,8 @@ void free_scene(DeviceState &d)
     for (void *p : d.scene_allocs) (void)hipFree(p);
     d.scene_allocs.clear();
     if (d.sph_cam) (void)hipFree(d.sph_cam);
-    d.sph_cam = nullptr;
+    if (d.grp_cam) (void)hipFree(d.grp_cam);
+    d.sph_cam = d.grp_cam = nullptr;
     const uchar4 *tex[RT_DEV_MAX_TEXTURES];
     int tw[RT_DEV_MAX_TEXTURES], th[RT_DEV_MAX_TEXTURES];
     memcpy(tex, d.scene.tex, sizeof tex);
@@ -135,50 +136,135 @@ int upload(rt_ctx *ctx, DeviceState &d, const std::vector<T> &host, const T **de
 }
 
 struct PackedScene {
-    std::vector<float4> sph, sph_f, pl, tri, geo, mat, light_pos, light_col;
+    std::vector<float4> sph, sph_f, grp_f, pl, tri, geo, mat, light_pos, light_col;
     std::vector<int> sph_orig, pl_orig, tri_orig, class_prefix;
     uint32_t textures_used = 0;
     float sph_center[3] = {0.f, 0.f, 0.f};
-    float sph_l1max = 0.f, sph_sc = 0.f;
+    float sph_l1max = 0.f, sph_sc = 0.f, grp_rmax = 0.f;
 };
+
+bool usable_sphere(const float4 &s)
+{
+    return std::isfinite(s.x) && std::isfinite(s.y) && std::isfinite(s.z) && std::isfinite(s.w) && s.w >= 0.f;
+}
+
+// Spatial order of the spheres: recursive median split along the widest axis of the
+// centres, the cut rounded to a whole number of 1024-sphere chunks, then of 64, then of
+// groups, so that every aligned group / chunk is spatially compact.  Spheres that can never
+// be hit (non-finite data) go last.  Deterministic: ties fall back on the host index.
+void spatial_order(const std::vector<float4> &sph, const std::vector<int> &orig, int *idx, size_t n)
+{
+    if (n <= (size_t)RT_GROUP) return;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = 0; i < n; i++) {
+        const float4 &s = sph[idx[i]];
+        const float c[3] = {s.x, s.y, s.z};
+        for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], c[k]), hi[k] = std::max(hi[k], c[k]);
+    }
+    int axis = 0;
+    for (int k = 1; k < 3; k++)
+        if (hi[k] - lo[k] > hi[axis] - lo[axis]) axis = k;
+    const size_t unit = n > 1024 ? 1024 : (n > 64 ? 64 : (size_t)RT_GROUP);
+    size_t half = ((n / 2 + unit - 1) / unit) * unit;
+    if (half >= n) half -= unit;
+    auto key = [&](int i) { const float4 &s = sph[i]; return axis == 0 ? s.x : (axis == 1 ? s.y : s.z); };
+    std::nth_element(idx, idx + half, idx + n, [&](int a, int b) {
+        const float ka = key(a), kb = key(b);
+        return ka < kb || (ka == kb && orig[a] < orig[b]);
+    });
+    spatial_order(sph, orig, idx, half);
+    spatial_order(sph, orig, idx + half, n - half);
+}
+
+void reorder_spheres(PackedScene &out)
+{
+    const size_t n = out.sph.size();
+    std::vector<int> good, bad;
+    for (size_t i = 0; i < n; i++) (usable_sphere(out.sph[i]) ? good : bad).push_back((int)i);
+    spatial_order(out.sph, out.sph_orig, good.data(), good.size());
+    good.insert(good.end(), bad.begin(), bad.end());
+    std::vector<float4> sph(n);
+    std::vector<int> orig(n);
+    for (size_t i = 0; i < n; i++) sph[i] = out.sph[good[i]], orig[i] = out.sph_orig[good[i]];
+    out.sph.swap(sph);
+    out.sph_orig.swap(orig);
+}
 
 // The sphere filter's view of the spheres (rt_kernels.hip, "Sphere filter"): centres relative
 // to the middle of their bounding box, W = r*r - k1*|p'|^2 from double arithmetic on the
-// rounded p', and the two bounds the kernels' margins are built from (rounded up).  A sphere
-// with non-finite data can never be hit (every comparison of objects.cs:116-121 fails) and
-// gets the never-pass entry.
-void build_filter_array(PackedScene &out)
+// rounded p'; one bounding ball per group of RT_GROUP spheres in the same form; and the
+// bounds the kernels' margins are built from (rounded up).  A sphere with non-finite data can
+// never be hit (every comparison of objects.cs:116-121 fails) and gets the never-pass entry,
+// as does the ball of a group without any usable sphere.
+void build_filter_arrays(PackedScene &out)
 {
     const size_t n = out.sph.size();
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    auto usable = [](const float4 &s) {
-        return std::isfinite(s.x) && std::isfinite(s.y) && std::isfinite(s.z) && std::isfinite(s.w);
-    };
     for (const float4 &s : out.sph) {
-        if (!usable(s)) continue;
+        if (!usable_sphere(s)) continue;
         const double c[3] = {s.x, s.y, s.z};
         for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], c[k]), hi[k] = std::max(hi[k], c[k]);
     }
-    for (int k = 0; k < 3; k++) out.sph_center[k] = lo[k] <= hi[k] ? (float)(0.5 * (lo[k] + hi[k])) : 0.f;
-    out.sph_f.assign(n, make_float4(0.f, 0.f, 0.f, -INFINITY));
-    double l1max = 0.0, p2max = 0.0, r2max = 0.0;
-    for (size_t i = 0; i < n; i++) {
-        const float4 &s = out.sph[i];
-        if (!usable(s)) continue;
-        const float px = (float)((double)s.x - (double)out.sph_center[0]);
-        const float py = (float)((double)s.y - (double)out.sph_center[1]);
-        const float pz = (float)((double)s.z - (double)out.sph_center[2]);
+    double cen[3];
+    for (int k = 0; k < 3; k++) {
+        out.sph_center[k] = lo[k] <= hi[k] ? (float)(0.5 * (lo[k] + hi[k])) : 0.f;
+        cen[k] = out.sph_center[k];
+    }
+    const float4 never = make_float4(0.f, 0.f, 0.f, -INFINITY);
+    out.sph_f.assign(n, never);
+    out.grp_f.assign(n / RT_GROUP, never);
+    double l1max = 0.0, p2max = 0.0, r2max = 0.0, grmax = 0.0;
+    auto entry = [&](const double c[3], double r2, float4 *dst) {
+        const float px = (float)(c[0] - cen[0]), py = (float)(c[1] - cen[1]), pz = (float)(c[2] - cen[2]);
         const double p2 = (double)px * px + (double)py * py + (double)pz * pz;
-        const float w = (float)((double)s.w - (double)RT_FILTER_K1 * p2);
-        if (!std::isfinite(w)) continue;
-        out.sph_f[i] = make_float4(px, py, pz, w);
+        const float w = (float)(r2 - (double)RT_FILTER_K1 * p2);
+        if (!std::isfinite(w)) return false;
+        *dst = make_float4(px, py, pz, w);
         l1max = std::max(l1max, std::fabs((double)px) + std::fabs((double)py) + std::fabs((double)pz));
         p2max = std::max(p2max, p2);
-        r2max = std::max(r2max, (double)s.w);
+        r2max = std::max(r2max, r2);
+        return true;
+    };
+    for (size_t i = 0; i < n; i++) {
+        const float4 &s = out.sph[i];
+        if (!usable_sphere(s)) continue;
+        const double c[3] = {s.x, s.y, s.z};
+        entry(c, (double)s.w, &out.sph_f[i]);
+    }
+    // Bounding balls: centre = middle of the members' extent, rounded the way the filter will
+    // see it; radius = max over members of |centre_i - centre| + r_i against that rounded
+    // centre, widened by 1e-6 relative.
+    for (size_t g = 0; g < n / RT_GROUP; g++) {
+        double blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        bool any = false;
+        for (size_t i = g * RT_GROUP; i < (g + 1) * RT_GROUP; i++) {
+            if (out.sph_f[i].w == -INFINITY) continue;
+            const float4 &s = out.sph[i];
+            const double c[3] = {s.x, s.y, s.z}, r = std::sqrt((double)s.w);
+            for (int k = 0; k < 3; k++) blo[k] = std::min(blo[k], c[k] - r), bhi[k] = std::max(bhi[k], c[k] + r);
+            any = true;
+        }
+        if (!any) continue;
+        double bc[3];
+        for (int k = 0; k < 3; k++) bc[k] = (double)(float)(0.5 * (blo[k] + bhi[k]) - cen[k]) + cen[k];
+        double rad = 0.0;
+        for (size_t i = g * RT_GROUP; i < (g + 1) * RT_GROUP; i++) {
+            if (out.sph_f[i].w == -INFINITY) continue;
+            const float4 &s = out.sph[i];
+            const double dx = s.x - bc[0], dy = s.y - bc[1], dz = s.z - bc[2];
+            rad = std::max(rad, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)s.w));
+        }
+        rad *= 1.0 + 1e-6;
+        if (entry(bc, rad * rad, &out.grp_f[g])) grmax = std::max(grmax, rad);
+        else {
+            // The ball cannot be represented: keep its members reachable with an always-pass ball.
+            out.grp_f[g] = make_float4(0.f, 0.f, 0.f, INFINITY);
+        }
     }
     const double up = 1.0 + 1e-6;   // far above the single rounding to float
     out.sph_l1max = (float)(l1max * up);
     out.sph_sc = (float)((2.0 * p2max + r2max) * up);
+    out.grp_rmax = (float)(grmax * up);
 }
 
 int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
@@ -243,7 +329,8 @@ int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
         out.sph.push_back(make_float4(0.f, 0.f, 0.f, -INFINITY));
         out.sph_orig.push_back(INT32_MAX);
     }
-    build_filter_array(out);
+    reorder_spheres(out);
+    build_filter_arrays(out);
     out.class_prefix[3 * (size_t)n + 0] = cs;
     out.class_prefix[3 * (size_t)n + 1] = cp;
     out.class_prefix[3 * (size_t)n + 2] = ct;
@@ -272,6 +359,7 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     int rc;
     if ((rc = upload(ctx, d, ps.sph, &sc.sph)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.sph_f, &sc.sph_f)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.grp_f, &sc.grp_f)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.sph_orig, &sc.sph_orig)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.pl, &sc.pl)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.pl_orig, &sc.pl_orig)) != RT_OK) return rc;
@@ -283,7 +371,10 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     if ((rc = upload(ctx, d, ps.light_col, &sc.light_col)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.class_prefix, &sc.class_prefix)) != RT_OK) return rc;
     HIP_TRY(ctx, hipMalloc((void **)&d.sph_cam, std::max<size_t>(ps.sph.size() * sizeof(float4), 16)));
+    HIP_TRY(ctx, hipMalloc((void **)&d.grp_cam, std::max<size_t>(ps.grp_f.size() * sizeof(float4), 16)));
     sc.sph_cam = d.sph_cam;
+    sc.grp_cam = d.grp_cam;
+    sc.grp_rmax = ps.grp_rmax;
     for (int k = 0; k < 3; k++) sc.sph_center[k] = ps.sph_center[k];
     sc.sph_l1max = ps.sph_l1max;
     sc.sph_sc = ps.sph_sc;
@@ -414,7 +505,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     d.timed = ctx->profiling && stream == d.stream;
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
     const int blocks = std::max(1, std::min((P + 255) / 256, d.num_cus * 8));
-    rtk_setup_camera(d.scene, dc, d.sph_cam, stream);
+    rtk_setup_camera(d.scene, dc, d.sph_cam, d.grp_cam, stream);
     rtk_primary(d.scene, dc, f, dev_pixels, blocks, stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[1], stream));
     // RT_HIP_LEVEL_KERNELS=1 (profiling aid): one launch per queue per level on this stream,

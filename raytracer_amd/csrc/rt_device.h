@@ -1,14 +1,17 @@
 // rt_device.h — data layout shared by the host side (rt_api.cpp) and the kernels
 // (rt_kernels.hip) of librt_hip.so.  gfx950 only.
 //
-// Scene in HBM (structure of arrays, one array per primitive class, each in the
-// host's insertion order; *_orig maps back to the host's primitive index, which is
-// what decides ties in closest-hit, MyApplication.cs:361):
+// Scene in HBM (structure of arrays, one array per primitive class; *_orig maps back to
+// the host's primitive index, which is what decides ties in closest-hit, MyApplication.cs:361,
+// and which occluder a shadow ray meets first, :373-378).  Planes and triangles keep the
+// host's order.  Spheres are stored in a spatial order: every aligned run of RT_GROUP spheres
+// is a compact group with a bounding ball, every aligned run of 1024 a compact chunk, so
+// that a wave whose rays all miss a ball skips the group (rt_kernels.hip, "Sphere filter").
 //   sph      float4 {cx, cy, cz, r*r}        one per sphere, what the exact evaluation reads
 //   sph_f    float4 {p'x, p'y, p'z, W}       the sphere filter's view of the same spheres:
 //                                            p' = centre - sph_center, W = r*r - k1*|p'|^2
-//                                            (rt_kernels.hip, "Sphere filter")
-//   sph_cam  float4 {p'x, p'y, p'z, -c''}    per frame: the filter's term for the camera origin
+//   grp_f    float4 {P'x, P'y, P'z, W}       one bounding ball per group, same form
+//   sph_cam, grp_cam  float4 {p', -c''}      per frame: the filter's term for the camera origin
 //   pl       float4 {nx, ny, nz, d}          one per plane
 //   tri      float4 x3 {v0}, {e1}, {e2}      e1 = v1-v0, e2 = v2-v0 (objects.cs:238-239)
 //   geo      float4 per host primitive: sphere centre or plane/triangle normal
@@ -31,9 +34,11 @@
 #define RT_MF_TEX_SHIFT   4        // texture slot + 1 in bits 4..7 (0 = none)
 #define RT_MF_TEX_MASK    0xF0
 
-// sph, sph_f, sph_cam and sph_orig are padded to a multiple of RT_SPH_PAD entries; the
-// padding is {0, 0, 0, -inf}, which no ray passes in the sphere filter.
-#define RT_SPH_PAD 8
+// sph, sph_f, sph_cam and sph_orig are padded to a multiple of RT_SPH_PAD entries (a whole
+// number of trips of bounding balls); the padding is {0, 0, 0, -inf}, which no ray passes in
+// the sphere filter, and so are the balls of groups made of padding only.
+#define RT_GROUP 8
+#define RT_SPH_PAD (RT_GROUP * 8)
 // k1 = 1 - 2^-18, the filter's relative margin (shared by the host's W and the kernels).
 #define RT_FILTER_K1 0.999996185302734375f
 
@@ -42,10 +47,13 @@ struct DevScene {
     int ns_padded;
     float sph_center[3];      // the filter's coordinate origin (centre of the spheres' bounding box)
     float sph_l1max;          // >= max over spheres of |p'|_1
-    float sph_sc;             // >= 2 max |p'|^2 + max r*r
+    float sph_sc;             // >= 2 max |p'|^2 + max r*r   (p', r over spheres and balls)
+    float grp_rmax;           // >= the largest bounding-ball radius
     const float4 *sph;
     const float4 *sph_f;
+    const float4 *grp_f;      // ns_padded / RT_GROUP bounding balls
     const float4 *sph_cam;    // per frame: {p', filter term} for the camera origin
+    const float4 *grp_cam;
     const int *sph_orig;
     const float4 *pl;
     const int *pl_orig;
@@ -119,7 +127,8 @@ struct DevFrame {
 };
 
 // Launch wrappers (rt_kernels.hip).  All enqueue on `stream` and return at once.
-void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, hipStream_t stream);
+void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, float4 *grp_cam,
+                      hipStream_t stream);
 void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels,
                  int grid_blocks, hipStream_t stream);
 // reflecting: the level's records that need a reflection trace (queue A) or the others (B).

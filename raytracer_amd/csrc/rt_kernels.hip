@@ -36,6 +36,7 @@
 #define FILTER_K1 RT_FILTER_K1               // 1 - 2^-18 = 1 - 64u
 #define FILTER_FM_SCALE 9.5367431640625e-07f // 2^-20   = 16u
 #define FILTER_E_SCALE 9.5367431640625e-07f  // 2^-20   = 16u
+#define FILTER_BALL_SLACK 1.5e-3f            // >= sqrt(28.6u) + 4.1u, see "Bounding balls"
 
 // ---------------------------------------------------------------------------------------
 // OpenTK.Mathematics Vector3 operators, restated (Dot / Cross / Length / Normalized).
@@ -174,6 +175,16 @@ __device__ __forceinline__ bool material_specular_nonzero(const DevScene &s, int
     return cload(s.mat, 3 * prim).w != 0.0f;
 }
 
+// A hit record goes to memory with a device-scope store (sc1: written through the XCD's L2),
+// so that workgroups on other XCDs can read it in the same launch without anybody having to
+// write a whole L2 back (k_trace_levels).
+__device__ __forceinline__ void store_record(float4 *dst, const f4raw v)
+{
+    // The s_nop covers the hazard "store of more than 64 bits, then a write of its data
+    // registers", which the compiler cannot see through inline assembly.
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+}
+
 // Append up to N new hit records per thread to level `level`, with ONE atomic per queue per
 // WORKGROUP: a single counter word takes only ~90 returning atomics per microsecond, and a
 // frame appends hundreds of thousands of waves' worth of records.  Every thread of the
@@ -222,8 +233,8 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
     for (int k = 0; k < N; k++) {
         if (valid[k]) {
             const int slot = is_a[k] ? (level * f.P + base_a + off[k]) : ((level + 1) * f.P - 1 - (base_b + off[k]));
-            f.recA[slot] = make_float4(hit[k].x, hit[k].y, hit[k].z, __int_as_float(prim[k]));
-            f.recB[slot] = make_float4(view[k].x, view[k].y, view[k].z, __int_as_float(parent[k]));
+            store_record(&f.recA[slot], f4raw{hit[k].x, hit[k].y, hit[k].z, __int_as_float(prim[k])});
+            store_record(&f.recB[slot], f4raw{view[k].x, view[k].y, view[k].z, __int_as_float(parent[k])});
         }
     }
     __syncthreads();  // blk may be reused by the caller's next trip
@@ -269,11 +280,27 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
 // Per sphere the words v of all rays are ANDed; a sphere whose combined word is >= 0 (as an
 // integer) in a lane goes to that lane's exact code, which repeats the reference's
 // evaluation literally (sphere_maybe / sphere_root).
+//
+// Bounding balls.  The spheres are stored in groups of RT_GROUP spatial neighbours, each with
+// a ball (P, R) such that |p_i - P| + r_i <= R for its members (rt_api.cpp).  Before a wave
+// evaluates a group's spheres it asks whether any lane's ray can meet the ball; if none can,
+// the group is skipped.  This loses no accepted pair: if the reference accepts (ray, sphere
+// i), then by (1) X_i <= 4.1u*B and by (2) the distance of p_i from the ray's line satisfies
+//   perp_i^2 = Q_i - X_i^2/|d|^2 <= r_i^2 + 28.6u*B^2,   B >= |o - p_i|,
+// (14.2u*Q from T, 8.3u*B^2 from x_ref vs X, 6.1u*Q from |d|^2 >= 1 - 6u), so with
+// sg = (sqrt(28.6u) + 4.1u)*B the ball of radius R' = R + sg around P has
+//   centre ahead or abeam (X_g <= 0):  perp_g <= perp_i + |P - p_i| <= R', i.e. X_g^2 >= Q_g - R'^2;
+//   centre behind (X_g > 0):           Q_g <= (|P - p_i| + perp_i + 4.1u*B)^2 <= R'^2: o is inside.
+// The ball test therefore is "x' >= 0 and x'^2 >= c''_g, or c''_g <= 0" with the same
+// evaluation and the same evaluation margins as above, for the sphere (P, R) and
+// E_g = E + 2*max R*sg + sg^2 in place of E (so that c''_g <= Q_g(1 - 14.2u) - R'^2):
+//   v1 = fma(x', x', -c''_g);  reject = (sign(v1) | sign(x')) & [c''_g > 0].
 // ---------------------------------------------------------------------------------------
 struct FilterOrigin {
-    f4raw lane;   // (Bx, By, Bz, C0): the filter loops' per-origin operand
-    f3 oc;        // o' = o - centre
-    float fm;     // front margin
+    f4raw lane;     // (Bx, By, Bz, C0): the sphere loops' per-origin operand
+    f4raw lane_g;   // (Bx, By, Bz, C0 of the bounding balls)
+    f3 oc;          // o' = o - centre
+    float fm;       // front margin
 };
 
 __device__ __forceinline__ FilterOrigin filter_origin(const DevScene &s, f3 o)
@@ -285,6 +312,10 @@ __device__ __forceinline__ FilterOrigin filter_origin(const DevScene &s, f3 o)
     const float e = FILTER_E_SCALE * __builtin_fmaf(2.0f, oo, s.sph_sc);
     const float k2 = 2.0f * FILTER_K1;
     fo.lane = f4raw{k2 * fo.oc.x, k2 * fo.oc.y, k2 * fo.oc.z, (FILTER_K1 * oo) - e};
+    // Balls: radius widened by sg (see "Bounding balls" above): E_g = E + 2*Rmax*sg + sg^2.
+    const float sg = FILTER_BALL_SLACK * (((fabsf(fo.oc.x) + fabsf(fo.oc.y)) + fabsf(fo.oc.z)) + s.sph_l1max);
+    const float eg = e + __builtin_fmaf(2.0f * s.grp_rmax, sg, sg * sg);
+    fo.lane_g = f4raw{fo.lane.x, fo.lane.y, fo.lane.z, (FILTER_K1 * oo) - eg};
     return fo;
 }
 
@@ -296,40 +327,53 @@ __device__ __forceinline__ f4raw filter_ray(const FilterOrigin &fo, f3 d)
 }
 
 // ---------------------------------------------------------------------------------------
-// setup_camera: every primary ray starts at camera.position, so the filter's per-sphere
-// term -c'' for that origin is computed once per frame: sph_cam[i] = {p', -c''}.
+// setup_camera: every primary ray starts at camera.position, so the filter's per-entry
+// term -c'' for that origin is computed once per frame for spheres and bounding balls:
+// sph_cam[i] = {p', -c''}, grp_cam[g] = {P', -c''_g}.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam, float4 *sph_cam)
+__global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam, float4 *sph_cam, float4 *grp_cam)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.ns_padded) return;
     const FilterOrigin fo = filter_origin(s, mk3(cam.pos[0], cam.pos[1], cam.pos[2]));
     const float4 pf = s.sph_f[i];
     const float chain = __builtin_fmaf(fo.lane.x, pf.x, __builtin_fmaf(fo.lane.y, pf.y, __builtin_fmaf(fo.lane.z, pf.z, pf.w)));
     sph_cam[i] = make_float4(pf.x, pf.y, pf.z, chain - fo.lane.w);   // padding: -inf, never passes
+    if (i < s.ns_padded / RT_GROUP) {
+        const float4 gf = s.grp_f[i];
+        const float gchain = __builtin_fmaf(fo.lane.x, gf.x, __builtin_fmaf(fo.lane.y, gf.y, __builtin_fmaf(fo.lane.z, gf.z, gf.w)));
+        grp_cam[i] = make_float4(gf.x, gf.y, gf.z, gchain - fo.lane_g.w);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
 // The filter loops themselves are gfx950 assembly with a fixed, VGPR-bank-conflict-free
 // register plan (filter_asm.inc, generated by tools/gen_filter_asm.py): hipcc's register
 // allocation ignores banks, and a three-source instruction with two sources in one bank
-// issues at half rate.  A loop walks the spheres staged in LDS, eight per trip; lanes whose
-// rays could hit a sphere of the trip queue one word in LDS and the loop goes on.  The
-// exact evaluation then runs here in C++ over each lane's (short) queue, in index order.
+// issues at half rate.  Per staged chunk a wave runs a GROUP loop over the chunk's bounding
+// balls, ORs the lanes' pass bits over the wave, runs a SEL loop over the groups some lane
+// may hit (lanes queue one word per trip with a candidate), and then evaluates each lane's
+// (short) queue exactly here in C++.
 
-// Spheres staged per workgroup: SPH_CHUNK filter entries {p', W} (or, for the primary kernel,
-// {p', -c''}) plus FA_LDS_SLACK never-pass entries for the loops' read-ahead.
+// Staged per workgroup: a chunk of SPH_CHUNK filter entries {p', W} (or, for the primary
+// kernel, {p', -c''}) and its SPH_CHUNK / RT_GROUP bounding balls plus FA_LDS_SLACK never-pass
+// entries for the GROUP loops' read-ahead.
 #define SPH_CHUNK 1024
-#define SPH_LDS_ENTRIES (SPH_CHUNK + FA_LDS_SLACK)
-// Candidate queues: QUEUE_SLOTS words per thread, slot-major (slot s of thread t at int index
-// 256*s + t).  A word names a trip of FA_TRIP spheres and which of them the lane's rays could
-// hit: (first index << 8) | reject mask, sphere m of the trip = bit 7-m, 0 = could hit.  A
-// loop returns early when some thread's queue is full.
+#define GRP_CHUNK (SPH_CHUNK / RT_GROUP)
+#define GRP_LDS_ENTRIES (GRP_CHUNK + FA_LDS_SLACK)
+#define GRP_WORDS (GRP_CHUNK / 32)
+// Queues: QUEUE_SLOTS words per thread, slot-major (slot s of thread t at int index 256*s + t).
+// GROUP loops leave trip j's reject mask (ball m of the trip = bit 7-m, 0 = could hit) in
+// slot j.  SEL loops append words that name a trip of FA_TRIP spheres and which of them the
+// lane's rays could hit: (first index << 8) | reject mask; they return early when some
+// thread's queue is full.
 #define QUEUE_SLOTS 16
 #define QUEUE_INTS (QUEUE_SLOTS * 256)
+static_assert(GRP_CHUNK / FA_TRIP <= QUEUE_SLOTS, "one queue slot per trip of balls");
+static_assert(RT_GROUP == FA_TRIP && RT_SPH_PAD == FA_TRIP * RT_GROUP, "a trip of a SEL loop is one group");
 
-// Walks a thread's queued words in index order: next() returns the next sphere index (local to
-// the staged chunk) the lane has to evaluate exactly, or -1 when its queue is exhausted.
+// Walks a thread's queued words: next() returns the next sphere index (local to the staged
+// chunk) the lane has to evaluate exactly, or -1 when its queue is exhausted.
 struct CandidateWalk {
     const int *cand;
     int nq, j, trip;
@@ -344,23 +388,154 @@ struct CandidateWalk {
             trip = (int)(w >> 8);
             pass = (w & 0xffu) ^ 0xffu;   // never 0: only lanes with a candidate queue a word
         }
-        const int b = 31 - __clz((int)pass);   // highest bit = lowest sphere index first
+        const int b = 31 - __clz((int)pass);
         pass &= ~(1u << b);
         return trip + 7 - b;
     }
 };
 
-__device__ __forceinline__ void stage_spheres(float4 *lds, const float4 *src, int base, int count)
+__device__ __forceinline__ void stage_chunk(float4 *lds, float4 *ldg, const float4 *sph_src, const float4 *grp_src,
+                                            int base, int count)
 {
-    for (int i = threadIdx.x; i < count; i += blockDim.x) lds[i] = src[base + i];
-    if (threadIdx.x < FA_LDS_SLACK) lds[count + threadIdx.x] = make_float4(0.f, 0.f, 0.f, -INFINITY);
+    for (int i = threadIdx.x; i < count; i += blockDim.x) lds[i] = sph_src[base + i];
+    const int ng = count / RT_GROUP;
+    for (int i = threadIdx.x; i < ng; i += blockDim.x) ldg[i] = grp_src[base / RT_GROUP + i];
+    if (threadIdx.x < FA_LDS_SLACK) ldg[ng + threadIdx.x] = make_float4(0.f, 0.f, 0.f, -INFINITY);
 }
-
 
 // Byte offset of an LDS object inside the workgroup's LDS allocation (what ds_read takes).
 __device__ __forceinline__ unsigned lds_offset(const void *p)
 {
     return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char *)p;
+}
+
+// Bitwise OR over the 64 lanes of a wave (all of them active), as a wave-uniform value:
+// butterfly inside each row of 16 lanes, then row 0 -> 1, 2 -> 3 and rows 0-1 -> 2-3, which
+// leaves the total in lane 63.
+__device__ __forceinline__ unsigned wave_or(unsigned v)
+{
+    int x = (int)v;
+    x |= __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);    // quad_perm:[1,0,3,2]
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);    // quad_perm:[2,3,0,1]
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xf, false);   // row_ror:4
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);   // row_ror:8
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane(x, 63);
+}
+
+// The generated loops for K rays; TRACE: the rays share a per-lane origin operand (`lane`),
+// otherwise the staged entries already hold -c'' (primary rays, K = 4).
+template <int K, bool TRACE>
+__device__ __forceinline__ void fa_group(int &i, unsigned &addr, unsigned &qaddr, const f4raw (&rq)[5],
+                                         const f4raw lane, const int cnt)
+{
+#define FA_RUN(NAME, ...)                                                  \
+    asm volatile(NAME##_ASM                                                \
+                 : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)     \
+                 : __VA_ARGS__, [cnt] "s"(cnt)                             \
+                 : NAME##_CLOBBERS)
+    if constexpr (!TRACE) {
+        static_assert(K == 4, "the primary loops take four rays");
+        FA_RUN(FA_PGROUP4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]));
+    } else {
+        static_assert(K >= 1 && K <= 5, "one loop per ray count 1..5");
+        if constexpr (K == 1) FA_RUN(FA_GROUP1, FA_DN0(rq[0]), FA_LANE(lane));
+        if constexpr (K == 2) FA_RUN(FA_GROUP2, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_LANE(lane));
+        if constexpr (K == 3) FA_RUN(FA_GROUP3, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_LANE(lane));
+        if constexpr (K == 4)
+            FA_RUN(FA_GROUP4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_LANE(lane));
+        if constexpr (K == 5)
+            FA_RUN(FA_GROUP5, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_DN4(rq[4]), FA_LANE(lane));
+    }
+#undef FA_RUN
+}
+
+template <int K, bool TRACE>
+__device__ __forceinline__ void fa_sel(unsigned &w, unsigned &qaddr, const f4raw (&rq)[5], const f4raw lane,
+                                       const int trip0, const unsigned addr0, const unsigned qlim)
+{
+#define FA_RUN(NAME, ...)                                                                   \
+    asm volatile(NAME##_ASM                                                                 \
+                 : [w] "+s"(w), [qaddr] "+v"(qaddr)                                         \
+                 : __VA_ARGS__, [trip0] "s"(trip0), [addr0] "s"(addr0), [qlim] "s"(qlim)    \
+                 : NAME##_CLOBBERS)
+    if constexpr (!TRACE) {
+        FA_RUN(FA_PSEL4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]));
+    } else {
+        if constexpr (K == 1) FA_RUN(FA_SEL1, FA_DN0(rq[0]), FA_LANE(lane));
+        if constexpr (K == 2) FA_RUN(FA_SEL2, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_LANE(lane));
+        if constexpr (K == 3) FA_RUN(FA_SEL3, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_LANE(lane));
+        if constexpr (K == 4)
+            FA_RUN(FA_SEL4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_LANE(lane));
+        if constexpr (K == 5)
+            FA_RUN(FA_SEL5, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_DN4(rq[4]), FA_LANE(lane));
+    }
+#undef FA_RUN
+}
+
+// One staged chunk of `cnt` spheres (a multiple of RT_SPH_PAD) for K rays per lane.
+// exact(li) is called, per lane, for every sphere li of the chunk the lane's rays could hit;
+// the order of the calls is not the spheres' host order.  Every lane of the wave must be
+// active.
+template <int K, bool TRACE, class Exact>
+__device__ __forceinline__ void walk_chunk(const float4 *lds, const float4 *ldg, int *cand, const int cnt,
+                                           const f4raw (&rq)[5], const f4raw lane_g, const f4raw lane,
+                                           Exact &&exact)
+{
+    const unsigned q0 = lds_offset(cand) + 4u * threadIdx.x;
+    const unsigned qlim = lds_offset(cand) + QUEUE_SLOTS * FA_QUEUE_STRIDE;
+    const int ngroups = cnt / RT_GROUP, ntrips = ngroups / FA_TRIP;
+#if !defined(RT_EXPERIMENT) || RT_EXPERIMENT < 3
+    {
+        int i = 0;
+        unsigned addr = lds_offset(ldg), qaddr = q0;
+        fa_group<K, TRACE>(i, addr, qaddr, rq, lane_g, ngroups);
+    }
+#endif
+    // Pass bits of 32 groups per word (bit 8t + b = group 8(4*word + t) + 7 - b), wave-wide.
+    static_assert(GRP_WORDS == 4, "four bitmap words per chunk");
+    unsigned words[GRP_WORDS];
+#pragma unroll
+    for (int wd = 0; wd < GRP_WORDS; wd++) {
+        unsigned bits = 0u;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int trip = 4 * wd + t;
+            if (trip < ntrips) bits |= (((unsigned)cand[trip * 256 + threadIdx.x] & 0xffu) ^ 0xffu) << (8 * t);
+        }
+        words[wd] = wave_or(bits);
+    }
+    // One copy of the SEL loop and of the exact evaluation in the code: the words rotate
+    // through w0 (the kernels' instruction footprint matters, see k_trace_levels).
+    unsigned w0 = words[0], w1 = words[1], w2 = words[2], w3 = words[3];
+#if defined(RT_EXPERIMENT) && RT_EXPERIMENT >= 2
+    w0 = w1 = w2 = w3 = 0u;
+#endif
+    int trip0 = 0;
+#pragma clang loop unroll(disable)
+    while ((w0 | w1 | w2 | w3) != 0u) {
+        if (w0 != 0u) {
+            unsigned qaddr = q0;
+            fa_sel<K, TRACE>(w0, qaddr, rq, lane, trip0, lds_offset(lds), qlim);
+            CandidateWalk walk(cand, (int)((qaddr - q0) / FA_QUEUE_STRIDE));
+#pragma clang loop unroll(disable)
+            for (;;) {
+                const int li = walk.next();
+                if (__ballot(li >= 0) == 0ull) break;
+#if !defined(RT_EXPERIMENT) || RT_EXPERIMENT < 1
+                if (li >= 0) exact(li);
+#endif
+            }
+        }
+        if (w0 == 0u) {
+            w0 = w1;
+            w1 = w2;
+            w2 = w3;
+            w3 = 0u;
+            trip0 += 32;
+        }
+    }
 }
 
 // GetRayDirection's per-pixel part, MyApplication.cs:438-449.
@@ -387,7 +562,8 @@ __device__ __forceinline__ f3 primary_direction(const DevCamera &cam, int px, in
 
 __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevFrame f, int32_t *pixels)
 {
-    __shared__ float4 lds[SPH_LDS_ENTRIES];
+    __shared__ float4 lds[SPH_CHUNK];
+    __shared__ float4 ldg[GRP_LDS_ENTRIES];
     __shared__ int cand[QUEUE_INTS];
     __shared__ int blk[12];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -399,7 +575,7 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
     const f3 o = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
     const FilterOrigin fo = filter_origin(s, o);
     if (single) {
-        stage_spheres(lds, s.sph_cam, 0, nsp);
+        stage_chunk(lds, ldg, s.sph_cam, s.grp_cam, 0, nsp);
         __syncthreads();
     }
     int candidates = 0;
@@ -411,7 +587,7 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
         int px[PRIM_PX], py[PRIM_PX];
         f3 d[PRIM_PX];
         float a[PRIM_PX], best_t[PRIM_PX];
-        int best_i[PRIM_PX];
+        int best_prim[PRIM_PX];   // host index of the closest sphere so far
 #pragma unroll
         for (int k = 0; k < PRIM_PX; k++) {
             const int x = x0 + (k & 1), y = y0 + (k >> 1);
@@ -421,54 +597,42 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
             py[k] = y < cam.row_end ? y : cam.row_end - 1;
             d[k] = primary_direction(cam, px[k], py[k]);
             a[k] = dot3(d[k], d[k]);
-            best_t[k] = RT_FLT_MAX;   // strict `<` within the class keeps the first of equals
-            best_i[k] = -1;
+            best_t[k] = RT_FLT_MAX;
+            best_prim[k] = INT_MAX;
         }
+        f4raw rq[5];
+#pragma unroll
+        for (int k = 0; k < PRIM_PX; k++) rq[k] = filter_ray(fo, d[k]);
+        rq[4] = rq[0];
         for (int base = 0; base < nsp; base += SPH_CHUNK) {
             const int cnt = min(SPH_CHUNK, nsp - base);
             if (!single) {
                 __syncthreads();
-                stage_spheres(lds, s.sph_cam, base, cnt);
+                stage_chunk(lds, ldg, s.sph_cam, s.grp_cam, base, cnt);
                 __syncthreads();
             }
-            const f4raw r0 = filter_ray(fo, d[0]), r1 = filter_ray(fo, d[1]), r2 = filter_ray(fo, d[2]),
-                        r3 = filter_ray(fo, d[3]);
-            const unsigned q0 = lds_offset(cand) + 4u * threadIdx.x;
-            const unsigned qlim = lds_offset(cand) + QUEUE_SLOTS * FA_QUEUE_STRIDE;
-            unsigned qaddr = q0, addr = lds_offset(lds);
-            int i = 0;
-            while (true) {
-                if (i < cnt)
-                    asm volatile(FA_PRIMARY4_ASM
-                                 : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
-                                 : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), [cnt] "s"(cnt), [qlim] "s"(qlim)
-                                 : FA_PRIMARY4_CLOBBERS);
-                // Exact evaluation of the queued spheres: objects.cs:112-121 literally.  Queue
-                // order = index order, so the strict `<` keeps the first of equal distances.
-                CandidateWalk walk(cand, (int)((qaddr - q0) / FA_QUEUE_STRIDE));
-                for (;;) {
-                    const int li = walk.next();
-                    if (__ballot(li >= 0) == 0ull) break;
-                    if (li >= 0) {
-                        candidates++;
-                        const float4 sp = s.sph[base + li];
-                        const f3 op = sub3(o, xyz(sp));
-                        const float c = dot3(op, op) - sp.w;
+            // Exact evaluation of a candidate: objects.cs:112-121 literally; among equal
+            // distances the lower host index wins, as the strict `<` of MyApplication.cs:361
+            // decides when the primitives are scanned in host order.
+            walk_chunk<PRIM_PX, false>(lds, ldg, cand, cnt, rq, fo.lane_g, fo.lane, [&](int li) {
+                candidates++;
+                const float4 sp = s.sph[base + li];
+                const f3 op = sub3(o, xyz(sp));
+                const float c = dot3(op, op) - sp.w;
+                int orig = -1;
 #pragma unroll
-                        for (int k = 0; k < PRIM_PX; k++) {
-                            const float xx = dot3(d[k], op);
-                            float t;
-                            if (sphere_maybe(xx, a[k] * c) && sphere_root(xx, c, a[k], t) && t < best_t[k] &&
-                                t > RT_EPS) {
-                                best_t[k] = t;
-                                best_i[k] = base + li;
-                            }
+                for (int k = 0; k < PRIM_PX; k++) {
+                    const float xx = dot3(d[k], op);
+                    float t;
+                    if (sphere_maybe(xx, a[k] * c) && sphere_root(xx, c, a[k], t) && t > RT_EPS && t <= best_t[k]) {
+                        if (orig < 0) orig = s.sph_orig[base + li];
+                        if (t < best_t[k] || orig < best_prim[k]) {
+                            best_t[k] = t;
+                            best_prim[k] = orig;
                         }
                     }
                 }
-                qaddr = q0;
-                if (i >= cnt) break;
-            }
+            });
         }
         bool rec_valid[PRIM_PX];
         int rec_prim[PRIM_PX], rec_parent[PRIM_PX];
@@ -477,7 +641,7 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
         for (int k = 0; k < PRIM_PX; k++) {
             Closest c;
             c.t = best_t[k];
-            c.prim = best_i[k] >= 0 ? cload(s.sph_orig, best_i[k]) : INT_MAX;
+            c.prim = best_prim[k];
             for (int j = 0; j < s.np; j++) {
                 const float4 pl = cload(s.pl, j);
                 const f3 n = xyz(pl);
@@ -524,7 +688,7 @@ struct Rays {
 };
 
 template <int LC, bool SEC>
-__device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, int *cand, const bool single,
+__device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, float4 *ldg, int *cand, const bool single,
                                          const f3 o, Rays<LC, SEC> &r, int &candidates)
 {
     constexpr int NR = LC + (SEC ? 1 : 0);
@@ -533,75 +697,56 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, int *ca
     const FilterOrigin fo = filter_origin(s, o);
     f4raw rq[5];
 #pragma unroll
+    for (int l = 0; l < 5; l++) rq[l] = f4raw{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
     for (int l = 0; l < LC; l++) rq[l] = filter_ray(fo, r.sh_d[l]);
     if (SEC) rq[LC] = filter_ray(fo, r.sec_d);
 
     float best_t = RT_FLT_MAX;
-    int best_i = -1;
+    int best_prim = INT_MAX;   // host index of the closest sphere so far
     const int nsp = s.ns_padded;
     for (int base = 0; base < nsp; base += SPH_CHUNK) {
         const int cnt = min(SPH_CHUNK, nsp - base);
         if (!single) {
             __syncthreads();
-            stage_spheres(lds, s.sph_f, base, cnt);
+            stage_chunk(lds, ldg, s.sph_f, s.grp_f, base, cnt);
             __syncthreads();
         }
-        const unsigned q0 = lds_offset(cand) + 4u * threadIdx.x;
-        const unsigned qlim = lds_offset(cand) + QUEUE_SLOTS * FA_QUEUE_STRIDE;
-        unsigned qaddr = q0, addr = lds_offset(lds);
-        int i = 0;
-        while (true) {
-#define FA_RUN(NAME, ...)                                                                 \
-    asm volatile(NAME##_ASM                                                               \
-                 : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)                    \
-                 : __VA_ARGS__, FA_LANE(fo.lane), [cnt] "s"(cnt), [qlim] "s"(qlim)           \
-                 : NAME##_CLOBBERS)
-            if (i < cnt) {
-                if constexpr (NR == 1) FA_RUN(FA_TRACE1, FA_DN0(rq[0]));
-                if constexpr (NR == 2) FA_RUN(FA_TRACE2, FA_DN0(rq[0]), FA_DN1(rq[1]));
-                if constexpr (NR == 3) FA_RUN(FA_TRACE3, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]));
-                if constexpr (NR == 4)
-                    FA_RUN(FA_TRACE4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]));
-                if constexpr (NR == 5)
-                    FA_RUN(FA_TRACE5, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_DN4(rq[4]));
-            }
-#undef FA_RUN
-            // Exact evaluation of the queued spheres, in index order (Sphere.Intersect
-            // objects.cs:112-121, literally).
-            CandidateWalk walk(cand, (int)((qaddr - q0) / FA_QUEUE_STRIDE));
-            for (;;) {
-                const int li = walk.next();
-                if (__ballot(li >= 0) == 0ull) break;
-                if (li >= 0) {
-                    candidates++;
-                    const float4 sp = s.sph[base + li];
-                    const f3 op = sub3(o, xyz(sp));
-                    const float c = dot3(op, op) - sp.w;
-                    float t;
-                    if (SEC) {
-                        const float x = dot3(r.sec_d, op);
-                        if (sphere_maybe(x, r.sec_a * c) && sphere_root(x, c, r.sec_a, t) && t < best_t &&
-                            t > RT_EPS) {
-                            best_t = t;
-                            best_i = base + li;
-                        }
-                    }
-#pragma unroll
-                    for (int l = 0; l < LC; l++) {
-                        const float x = dot3(r.sh_d[l], op);
-                        if (sphere_maybe(x, r.sh_a[l] * c) && sphere_root(x, c, r.sh_a[l], t) && t > RT_EPS &&
-                            t < r.sh_dist[l])
-                            r.sh_first[l] = min(r.sh_first[l], s.sph_orig[base + li]);
+        // Exact evaluation of a candidate (Sphere.Intersect objects.cs:112-121, literally).
+        // Closest hit: among equal distances the lower host index wins (MyApplication.cs:361);
+        // shadow rays: the lowest host index among the occluders is the one the reference
+        // meets first (MyApplication.cs:373-378).
+        walk_chunk<NR, true>(lds, ldg, cand, cnt, rq, fo.lane_g, fo.lane, [&](int li) {
+            candidates++;
+            const float4 sp = s.sph[base + li];
+            const f3 op = sub3(o, xyz(sp));
+            const float c = dot3(op, op) - sp.w;
+            int orig = -1;
+            float t;
+            if (SEC) {
+                const float x = dot3(r.sec_d, op);
+                if (sphere_maybe(x, r.sec_a * c) && sphere_root(x, c, r.sec_a, t) && t > RT_EPS && t <= best_t) {
+                    orig = s.sph_orig[base + li];
+                    if (t < best_t || orig < best_prim) {
+                        best_t = t;
+                        best_prim = orig;
                     }
                 }
             }
-            qaddr = q0;
-            if (i >= cnt) break;
-        }
+#pragma unroll
+            for (int l = 0; l < LC; l++) {
+                const float x = dot3(r.sh_d[l], op);
+                if (sphere_maybe(x, r.sh_a[l] * c) && sphere_root(x, c, r.sh_a[l], t) && t > RT_EPS &&
+                    t < r.sh_dist[l]) {
+                    if (orig < 0) orig = s.sph_orig[base + li];
+                    r.sh_first[l] = min(r.sh_first[l], orig);
+                }
+            }
+        });
     }
     if (SEC) {
         r.sec.t = best_t;
-        r.sec.prim = best_i >= 0 ? cload(s.sph_orig, best_i) : INT_MAX;
+        r.sec.prim = best_prim;
     }
     // ---- planes --------------------------------------------------------------------
     for (int j = 0; j < s.np; j++) {
@@ -652,7 +797,7 @@ struct TestCount {
 
 // One chunk of LC lights (plus the reflection ray when SEC) for one record.
 template <int LC, bool SEC>
-__device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, int *cand, const bool single, const f3 hit,
+__device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, float4 *ldg, int *cand, const bool single, const f3 hit,
                                             const f3 view, const f3 normal, int l0, uint32_t &mask_word,
                                             Closest &sec_out, f3 &sec_dir, TestCount &tc)
 {
@@ -673,7 +818,7 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, int 
         r.sec.t = RT_FLT_MAX;
         r.sec.prim = INT_MAX;
     }
-    traverse<LC, SEC>(s, lds, cand, single, hit, r, tc.exact);
+    traverse<LC, SEC>(s, lds, ldg, cand, single, hit, r, tc.exact);
 #pragma unroll
     for (int l = 0; l < LC; l++) {
         const bool occluded = r.sh_first[l] != INT_MAX;
@@ -700,7 +845,7 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, int 
 // instance is used, which needs far fewer registers.  n = records in the queue.
 // Every thread of the workgroup must call it (barriers inside).
 template <bool SEC, int LCMAX>
-__device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f, float4 *lds, int *cand, int *blk,
+__device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f, float4 *lds, float4 *ldg, int *cand, int *blk,
                                            const bool single, const int level, const int tile, const int n,
                                            TestCount &tc)
 {
@@ -725,19 +870,19 @@ __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f,
     while (l0 < nl || (SEC && first)) {
         const int rem = nl - l0;
         if (LCMAX >= 4 && rem >= 4) {
-            if (SEC && first) trace_chunk<LCMAX >= 4 ? 4 : 2, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-            else trace_chunk<LCMAX >= 4 ? 4 : 2, false>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            if (SEC && first) trace_chunk<LCMAX >= 4 ? 4 : 2, true>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            else trace_chunk<LCMAX >= 4 ? 4 : 2, false>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
             l0 += 4;
         } else if (rem >= 2) {
-            if (SEC && first) trace_chunk<2, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-            else trace_chunk<2, false>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            if (SEC && first) trace_chunk<2, true>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            else trace_chunk<2, false>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
             l0 += 2;
         } else if (rem == 1) {
-            if (SEC && first) trace_chunk<1, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-            else trace_chunk<1, false>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            if (SEC && first) trace_chunk<1, true>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            else trace_chunk<1, false>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
             l0 += 1;
         } else {
-            trace_chunk<0, true>(s, lds, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            trace_chunk<0, true>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
         }
         first = false;
         if (l0 > 0 && ((l0 & 31) == 0 || l0 >= nl)) {
@@ -778,20 +923,21 @@ __device__ __forceinline__ void flush_test_counts(const DevFrame &f, const TestC
 template <bool SEC, int LCMAX>
 __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level)
 {
-    __shared__ float4 lds[SPH_LDS_ENTRIES];
+    __shared__ float4 lds[SPH_CHUNK];
+    __shared__ float4 ldg[GRP_LDS_ENTRIES];
     __shared__ int cand[QUEUE_INTS];
     __shared__ int blk[12];
     const int n = SEC ? f.cnt[2 * level] : f.cnt[2 * level + 1];
     const int ntiles = (n + 255) >> 8;
     const bool single = s.ns_padded <= SPH_CHUNK;
     if (single && (int)blockIdx.x < ntiles) {
-        stage_spheres(lds, s.sph_f, 0, s.ns_padded);
+        stage_chunk(lds, ldg, s.sph_f, s.grp_f, 0, s.ns_padded);
         __syncthreads();
     }
     TestCount tc = {0, 0, 0, 0};
     // Workgroup-uniform trip count: the sphere chunks are staged between barriers.
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
-        trace_tile<SEC, LCMAX>(s, f, lds, cand, blk, single, level, tile, n, tc);
+        trace_tile<SEC, LCMAX>(s, f, lds, ldg, cand, blk, single, level, tile, n, tc);
     flush_test_counts(f, tc);
 }
 
@@ -805,15 +951,22 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
 // chip therefore stays full across level boundaries, where separate launches per level
 // leave it to a shrinking tail of workgroups.
 //
-// Protocol: after a workgroup barrier, thread 0 of a workgroup that finished an A tile
-// fences at device scope and counts the tile as done; the one that counts the level's last
-// tile publishes open_level = k+1.  Takers (thread 0) read open_level and the record counts
-// with device-scope atomic loads and fence before the workgroup barrier that hands the job
-// to the other lanes.  The chain ends at the first
-// open level without A records (level max_depth never has any); a workgroup leaves when
-// the chain has ended and no B tile is left to claim.  A workgroup that waits longer than
-// SCHED_SPIN_LIMIT polls for a level to open sets sched->error and leaves (the host
-// reports it) so that no launch can spin forever.
+// Protocol (cache maintenance is the cost to avoid: a device-scope release fence writes the
+// whole L2 of the XCD back and an acquire fence invalidates it, and a fence pair per tile was
+// measured at ~45 us per tile, more than the tile's own work):
+//   * hit records are written with device-scope stores (push_records, store_record), which
+//     go through to memory, and counted with device-scope atomics; a workgroup that finished
+//     an A tile waits for its stores (vmcnt 0 in every wave, then a barrier) and only then
+//     counts the tile as done; the workgroup that counts the level's last tile publishes
+//     open_level = k+1.  No write-back fence is needed.
+//   * a taker (thread 0) reads open_level with a device-scope load on every claim; when it
+//     sees a level it has not seen before it invalidates the caches ONCE (acquire fence), reads
+//     that level's record counts, and only then hands tiles of that level to the workgroup.
+//     Nobody reads a level's slots before the level is open, so no stale line can survive.
+// The chain ends at the first open level without A records (level max_depth never has any);
+// a workgroup leaves when the chain has ended and no B tile is left to claim.  A workgroup
+// that waits longer than SCHED_SPIN_LIMIT polls for a level to open sets sched->error and
+// leaves (the host reports it) so that no launch can spin forever.
 // ---------------------------------------------------------------------------------------
 #define SCHED_JOB_EXIT 0
 #define SCHED_JOB_A 1
@@ -825,59 +978,83 @@ __device__ __forceinline__ int sched_load(const int *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Thread 0's view of the schedule.
+struct Taker {
+    int seen_open;        // levels <= seen_open: caches invalidated after they opened, counts read
+    int b_level;          // lowest level whose B queue may still hold an unclaimed tile
+    bool a_left;          // level seen_open may still hold an unclaimed A tile
+    unsigned spins;
+};
+
 template <int LCMAX>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 k_trace_levels(DevScene s, DevFrame f)
 {
-    __shared__ float4 lds[SPH_LDS_ENTRIES];
+    __shared__ float4 lds[SPH_CHUNK];
+    __shared__ float4 ldg[GRP_LDS_ENTRIES];
     __shared__ int cand[QUEUE_INTS];
     __shared__ int blk[12];
     __shared__ int job[4];
+    __shared__ int lv_a[RT_DEV_MAX_LEVELS], lv_b[RT_DEV_MAX_LEVELS];   // record counts of the seen levels (thread 0)
     DevSched *const sc = f.sched;
     const int D = f.max_depth;
     const bool single = s.ns_padded <= SPH_CHUNK;
     bool staged = false;
     TestCount tc = {0, 0, 0, 0};
+    Taker tk = {-1, 0, false, 0u};
     for (;;) {
         if (threadIdx.x == 0) {
             int kind = SCHED_JOB_EXIT, lvl = 0, tile = 0, n = 0;
-            unsigned spins = 0;
             for (;;) {
-                const int open = __hip_atomic_load(&sc->open_level, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                const int na = open < D ? sched_load(&f.cnt[2 * open]) : 0;
-                const int tiles_a = (na + 255) >> 8;
-                if (tiles_a > 0 && sched_load(&sc->next_a[open]) < tiles_a) {
-                    const int t = atomicAdd(&sc->next_a[open], 1);
-                    if (t < tiles_a) {
-                        kind = SCHED_JOB_A, lvl = open, tile = t, n = na;
-                        break;
+                // What this workgroup believes is claimable, A tiles of the newest level first.
+                int *ctr = nullptr;
+                int cand_kind = SCHED_JOB_EXIT, cand_lvl = 0, cand_n = 0;
+                if (tk.a_left) {
+                    ctr = &sc->next_a[tk.seen_open];
+                    cand_kind = SCHED_JOB_A, cand_lvl = tk.seen_open, cand_n = lv_a[tk.seen_open];
+                } else {
+                    while (tk.b_level <= tk.seen_open && lv_b[tk.b_level] < 0) tk.b_level++;
+                    if (tk.b_level <= tk.seen_open) {
+                        ctr = &sc->next_b[tk.b_level];
+                        cand_kind = SCHED_JOB_B, cand_lvl = tk.b_level, cand_n = lv_b[tk.b_level];
                     }
                 }
-                const int top = open < D ? open : D;
-                for (int j = 0; j <= top && kind == SCHED_JOB_EXIT; j++) {
-                    const int nb = sched_load(&f.cnt[2 * j + 1]);
-                    const int tiles_b = (nb + 255) >> 8;
-                    if (sched_load(&sc->next_b[j]) < tiles_b) {
-                        const int t = atomicAdd(&sc->next_b[j], 1);
-                        if (t < tiles_b) kind = SCHED_JOB_B, lvl = j, tile = t, n = nb;
+                // One round trip: the level check and the claim travel together.
+                const int open = sched_load(&sc->open_level);
+                const int t = ctr ? atomicAdd(ctr, 1) : 0;
+                const bool claimed = ctr && t < ((cand_n + 255) >> 8);
+                if (ctr && !claimed) {   // that queue is exhausted
+                    if (cand_kind == SCHED_JOB_A) tk.a_left = false;
+                    else lv_b[cand_lvl] = -1;
+                }
+                const bool opened = open > tk.seen_open;
+                if (opened) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // once per level per workgroup
+                    for (int k = tk.seen_open + 1; k <= open; k++) {
+                        lv_a[k] = k < D ? sched_load(&f.cnt[2 * k]) : 0;
+                        const int nb = sched_load(&f.cnt[2 * k + 1]);
+                        lv_b[k] = nb > 0 ? nb : -1;   // -1: nothing (left) to claim
                     }
+                    tk.seen_open = open;
+                    tk.a_left = lv_a[open] > 0;
                 }
-                if (kind != SCHED_JOB_EXIT) break;
-                if (tiles_a == 0) break;   // the chain has ended and every B tile is taken: leave
-                // A tiles of level `open` are in flight: wait for the next level to open.
-                while (sched_load(&sc->open_level) == open && spins < SCHED_SPIN_LIMIT) {
-                    spins++;
-                    __builtin_amdgcn_s_sleep(127);
-                    __builtin_amdgcn_s_sleep(127);
-                    __builtin_amdgcn_s_sleep(127);
-                    __builtin_amdgcn_s_sleep(127);
+                if (claimed) {
+                    kind = cand_kind, lvl = cand_lvl, tile = t, n = cand_n;
+                    break;
                 }
-                if (spins >= SCHED_SPIN_LIMIT) {
+                if (ctr || opened) continue;
+                // Nothing to claim in the levels seen so far.
+                if (tk.seen_open >= 0 && lv_a[tk.seen_open] == 0) break;   // the chain has ended: leave
+                // A tiles of the newest level are in flight (or the frame has not started): wait.
+                if (++tk.spins >= SCHED_SPIN_LIMIT) {
                     atomicExch(&sc->error, 1);
                     break;
                 }
+                __builtin_amdgcn_s_sleep(127);
+                __builtin_amdgcn_s_sleep(127);
+                __builtin_amdgcn_s_sleep(127);
+                __builtin_amdgcn_s_sleep(127);
             }
-            __threadfence();   // acquire: what other workgroups published before open_level moved
             job[0] = kind;
             job[1] = lvl;
             job[2] = tile;
@@ -887,23 +1064,24 @@ k_trace_levels(DevScene s, DevFrame f)
         const int kind = job[0], lvl = job[1], tile = job[2], n = job[3];
         if (kind == SCHED_JOB_EXIT) break;
         if (single && !staged) {
-            stage_spheres(lds, s.sph_f, 0, s.ns_padded);
+            stage_chunk(lds, ldg, s.sph_f, s.grp_f, 0, s.ns_padded);
             staged = true;
         }
         __syncthreads();   // job[] read by all, spheres staged
         if (kind == SCHED_JOB_A) {
-            trace_tile<true, LCMAX>(s, f, lds, cand, blk, single, lvl, tile, n, tc);
-            __syncthreads();   // every lane's child records are written ...
+            trace_tile<true, LCMAX>(s, f, lds, ldg, cand, blk, single, lvl, tile, n, tc);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's record stores have reached memory
+            __syncthreads();
             if (threadIdx.x == 0) {
-                __threadfence();   // ... and released to the device before the tile counts as done
+#ifdef RT_SCHED_RELEASE_FENCE
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
                 const int tiles_a = (n + 255) >> 8;
-                if (atomicAdd(&sc->done_a[lvl], 1) + 1 == tiles_a) {
-                    __threadfence();
-                    __hip_atomic_store(&sc->open_level, lvl + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if (atomicAdd(&sc->done_a[lvl], 1) + 1 == tiles_a)
+                    __hip_atomic_store(&sc->open_level, lvl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
-            trace_tile<false, LCMAX>(s, f, lds, cand, blk, single, lvl, tile, n, tc);
+            trace_tile<false, LCMAX>(s, f, lds, ldg, cand, blk, single, lvl, tile, n, tc);
         }
     }
     flush_test_counts(f, tc);
@@ -1044,10 +1222,12 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
 // ---------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------
-void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, hipStream_t stream)
+void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, float4 *grp_cam,
+                      hipStream_t stream)
 {
     if (s.ns_padded <= 0) return;
-    hipLaunchKernelGGL(k_setup_camera, dim3((s.ns_padded + 255) / 256), dim3(256), 0, stream, s, cam, sph_cam);
+    hipLaunchKernelGGL(k_setup_camera, dim3((s.ns_padded + 255) / 256), dim3(256), 0, stream, s, cam, sph_cam,
+                       grp_cam);
 }
 
 void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels, int grid_blocks,

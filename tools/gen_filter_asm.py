@@ -21,6 +21,7 @@ filter".
 Register plan (VGPR numbers; b0..b3 = bank):
   v[4k : 4k+3]      ray k < 5:   (e_k b0, dx b1, dy b2, dz b3)
   v[20:23]          lane:        (Bx b0, By b1, Bz b2, C0 b3)       trace loops only
+  v24               LDS address of the trip being fetched (SEL loops)
   v25 (b1)          the trip's reject mask, then the queued word
   v[26+4u : 29+4u]  sphere set 0, u < 4:  (px b2, py b3, pz b0, w b1);  -c'' replaces w
   v[42+4u : 45+4u]  sphere set 1
@@ -28,28 +29,35 @@ Register plan (VGPR numbers; b0..b3 = bank):
       i < 4:  SA(i) b2, SB(i) b3   temporaries of sphere i's -c'' chain; later SB holds v of ray
                                    2 and SA the sphere's combined verdict word
       i < 6:  TA(i) b0, TB(i) b1   temporaries of ray chain i
-  s[98:99]          saved exec mask during the append, s97 scratch
+      4..6 :  VT(2(i-4)) b2, VT(2(i-4)+1) b3   v1 of ray chain j (GROUP loops)
+  s[98:99]          saved exec mask during the append, s93..s97 scratch
 
-A loop walks the staged spheres from index i in batches of 4, two batches per trip with the
-two register sets in ping-pong (the LDS reads of one batch fly while the other is computed).
-The sign bits of a trip's 8 verdict words are shifted into one reject mask per lane (sphere m
-of the trip = bit 7-m, 1 = cannot hit), tested with ONE compare and branch per trip.  Lanes
-with a clear bit append the word (i << 8 | mask) to their own candidate queue in LDS
-(slot-major: slot s of thread t at qaddr0 + 1024*s + 4*t, so a wave's write is conflict-free)
-and the loop goes on; the C++ caller runs the exact evaluation over each lane's queue
-afterwards, in index order.  The loop leaves early only when some lane's queue is full (its
-qaddr has reached qlim); the caller then drains the queues and re-enters at the returned
-index.
+A trip handles 8 consecutive entries of the staged array in two batches of 4, the two register
+sets in ping-pong (the LDS reads of one batch fly while the other is computed).  The sign bits
+of a trip's 8 verdict words are shifted into one reject mask per lane (entry m of the trip =
+bit 7-m, 1 = cannot hit).  Two kinds of loop are generated:
 
-Behind the last batch there must be 4 more entries (any finite or infinite values): the loop
-always reads one batch ahead.  The loop is entered at multiples of 8 spheres and cnt is a
-multiple of 8.
+  GROUP loops  walk the array of bounding balls (one ball per 8 spheres) from entry i to cnt,
+      trip after trip, and store every trip's mask to the lane's queue slot of that trip
+      (slot s of thread t at qaddr0 + 1024*s + 4*t, so a wave's write is conflict-free).
+      The verdict is "the ray's half-line meets the ball":
+          v1 = fma(x', x', -c'');  reject = (sign(v1) | sign(x')) & sign(c'')
+      Behind the last trip there must be 4 more entries (the loop reads one batch ahead).
+  SEL loops    run the sphere trips named by a wave-uniform 32-bit bitmap w (bit b = trip
+      trip0 + (b ^ 7)), lowest bit first; the first batch of the next selected trip is
+      fetched while the second batch of the current one is computed.  Lanes with a clear
+      mask bit append the word (first sphere index << 8 | mask) to their queue, tested with
+      ONE compare and branch per trip, and the loop goes on; the C++ caller runs the exact
+      evaluation over each lane's queue afterwards.  The loop leaves early when some lane's
+      queue is full (its qaddr has reached qlim), with the trips not yet run left in w; the
+      caller drains the queues and re-enters.
 """
 import os
 
 NB = 4   # spheres per batch
 DN = lambda k: 4 * k
 LANE = 20
+VADDR = 24
 MASK = 25
 SET = (lambda u: 26 + 4 * u, lambda u: 42 + 4 * u)
 QUAD = lambda i: 58 + 4 * i
@@ -57,6 +65,7 @@ SA = lambda u: QUAD(u)
 SB = lambda u: QUAD(u) + 1
 TA = lambda j: QUAD(j) + 2
 TB = lambda j: QUAD(j) + 3
+VT = lambda j: QUAD(4 + j // 2) + (j % 2)
 QSTRIDE = 1024   # bytes between a thread's consecutive queue slots (256 threads x 4 B)
 VARIANT = os.environ.get("FA_VARIANT", "")   # experiments only (tools/filter_loop_bench.hip)
 
@@ -92,8 +101,8 @@ def group_size(K):
     return {1: 4, 2: 2, 3: 2, 4: 1, 5: 1}[K]
 
 
-def phase(L, K, trace, cur, ph):
-    """Shifts the reject bits of the NB spheres in register set `cur` into MASK."""
+def phase(L, K, trace, cur, ph, ball=False):
+    """Shifts the reject bits of the NB entries in register set `cur` into MASK."""
     s = SET[cur]
     px, py, pz, w = (lambda u: s(u)), (lambda u: s(u) + 1), (lambda u: s(u) + 2), (lambda u: s(u) + 3)
     if trace:
@@ -126,10 +135,22 @@ def phase(L, K, trace, cur, ph):
             L.append(fma(TB(tmp[u, k]), DN(k) + 2, py(u), TA(tmp[u, k])))
         for (u, k) in chains:
             L.append(fma(TA(tmp[u, k]), DN(k) + 3, pz(u), TB(tmp[u, k])))
-        for (u, k) in chains:
-            x = TA(tmp[u, k])
-            check3(x, w(u))
-            L.append(f"v_fma_f32 v{vreg(u, k)}, v{x}, |v{x}|, v{w(u)}")
+        if ball:
+            for (u, k) in chains:
+                x = TA(tmp[u, k])
+                check3(x, w(u))
+                L.append(f"v_fma_f32 v{VT(tmp[u, k])}, v{x}, v{x}, v{w(u)}")
+            for (u, k) in chains:
+                j = tmp[u, k]
+                check3(VT(j), TA(j), w(u))
+                # reject = (sign(v1) | sign(x')) & [c'' > 0]; the register holds -c'', whose sign
+                # bit is set exactly when c'' > 0:  (a | b) & c = 0xa8
+                L.append(f"v_bitop3_b32 v{vreg(u, k)}, v{VT(j)}, v{TA(j)}, v{w(u)} bitop3:0xa8")
+        else:
+            for (u, k) in chains:
+                x = TA(tmp[u, k])
+                check3(x, w(u))
+                L.append(f"v_fma_f32 v{vreg(u, k)}, v{x}, |v{x}|, v{w(u)}")
         for u in us:
             acc = SA(u)
             if K == 2:
@@ -155,12 +176,69 @@ def loads(L, which, byte_offset, first=False):
         L.append(f"ds_read_b128 v[{r}:{r + 3}], %[addr] offset:{byte_offset + 16 * u}")
 
 
-def append_block(L):
-    """After both phases of a trip: lanes with a clear bit in MASK queue (i << 8 | MASK)."""
+def group_loop(K, trace):
+    """GROUP loop: every trip of the ball array from entry i to cnt; masks stored per trip."""
+    L = []
+    loads(L, 0, 0, first=True)
+    L.append(".LFA_LOOP%=:")
+    L.append("s_waitcnt lgkmcnt(0)")
+    loads(L, 1, 16 * NB)
+    phase(L, K, trace, 0, 0, ball=True)
+    L.append("s_waitcnt lgkmcnt(0)")
+    loads(L, 0, 32 * NB)
+    phase(L, K, trace, 1, 1, ball=True)
+    L.append(f"ds_write_b32 %[qaddr], v{MASK}")
+    L.append(f"v_add_u32 %[qaddr], {QSTRIDE}, %[qaddr]")
+    L.append(f"s_add_u32 %[i], %[i], {2 * NB}")
+    L.append(f"v_add_u32 %[addr], {32 * NB}, %[addr]")
+    L.append("s_cmp_lt_i32 %[i], %[cnt]")
+    L.append("s_cbranch_scc1 .LFA_LOOP%=")
+    L.append("s_waitcnt lgkmcnt(0)")          # nothing of ours may still be in flight outside
+    return L
+
+
+def next_trip(L, dst):
+    """Takes the lowest set bit of the bitmap: dst = its trip, v24 = the trip's LDS address."""
+    L.append("s_ff1_i32_b32 s96, %[w]")
+    L.append("s_bitset0_b32 %[w], s96")
+    L.append(f"s_xor_b32 {dst}, s96, 7")
+    L.append(f"s_add_u32 {dst}, {dst}, %[trip0]")
+    L.append(f"s_lshl_b32 s94, {dst}, {(2 * NB * 16).bit_length() - 1}")
+    L.append("s_add_u32 s94, s94, %[addr0]")
+    L.append(f"v_mov_b32 v{VADDR}, s94")
+
+
+def sel_loads(L, which, byte_offset):
+    for u in range(NB):
+        r = SET[which](u)
+        L.append(f"ds_read_b128 v[{r}:{r + 3}], v{VADDR} offset:{byte_offset + 16 * u}")
+
+
+def sel_loop(K, trace):
+    """SEL loop: the sphere trips named by the bitmap w; s95 = current trip, s93 = next or -1."""
+    L = []
+    next_trip(L, "s95")
+    sel_loads(L, 0, 0)
+    L.append(".LFA_LOOP%=:")
+    sel_loads(L, 1, 16 * NB)
+    L.append(f"s_waitcnt lgkmcnt({NB})")      # LDS returns in order: the first batch has arrived
+    phase(L, K, trace, 0, 0)
+    L.append("s_mov_b32 s93, -1")
+    L.append("s_cmp_eq_u32 %[w], 0")
+    L.append("s_cbranch_scc1 .LFA_LAST%=")
+    next_trip(L, "s93")
+    L.append("s_waitcnt lgkmcnt(0)")
+    sel_loads(L, 0, 0)                         # the next trip's first batch flies during phase 1
+    L.append("s_branch .LFA_PH1%=")
+    L.append(".LFA_LAST%=:")
+    L.append("s_waitcnt lgkmcnt(0)")
+    L.append(".LFA_PH1%=:")
+    phase(L, K, trace, 1, 1)
+    # lanes with a clear bit in MASK queue (first sphere index << 8 | MASK)
     L.append(f"v_cmp_ne_u32 vcc, 0xff, v{MASK}")
     L.append("s_cbranch_vccz .LFA_NOAPP%=")
     L.append("s_mov_b64 s[98:99], exec")
-    L.append("s_lshl_b32 s97, %[i], 8")
+    L.append("s_lshl_b32 s97, s95, 11")
     L.append("s_and_b64 exec, exec, vcc")
     L.append(f"v_or_b32 v{MASK}, s97, v{MASK}")
     L.append(f"ds_write_b32 %[qaddr], v{MASK}")
@@ -169,30 +247,17 @@ def append_block(L):
     L.append("v_cmp_le_u32 vcc, %[qlim], %[qaddr]")
     L.append("s_cbranch_vccnz .LFA_FULL%=")
     L.append(".LFA_NOAPP%=:")
-
-
-def gen_loop(K, trace):
-    L = []
-    loads(L, 0, 0, first=True)
-    if "nolds" in VARIANT:
-        loads(L, 1, 16 * NB, first=True)
-    L.append(".LFA_LOOP%=:")
-    L.append("s_waitcnt lgkmcnt(0)")
-    loads(L, 1, 16 * NB)
-    phase(L, K, trace, 0, 0)
-    L.append("s_waitcnt lgkmcnt(0)")
-    loads(L, 0, 32 * NB)
-    phase(L, K, trace, 1, 1)
-    append_block(L)
-    L.append(f"s_add_u32 %[i], %[i], {2 * NB}")
-    L.append(f"v_add_u32 %[addr], {32 * NB}, %[addr]")
-    L.append("s_cmp_lt_i32 %[i], %[cnt]")
-    L.append("s_cbranch_scc1 .LFA_LOOP%=")
+    L.append("s_mov_b32 s95, s93")
+    L.append("s_cmp_lt_i32 s93, 0")
+    L.append("s_cbranch_scc0 .LFA_LOOP%=")
     L.append("s_branch .LFA_DONE%=")
-    # A queue is (nearly) full: return the index of the next trip.
+    # A queue is full: the trip already being fetched goes back into the bitmap.
     L.append(".LFA_FULL%=:")
-    L.append(f"s_add_u32 %[i], %[i], {2 * NB}")
-    L.append(f"v_add_u32 %[addr], {32 * NB}, %[addr]")
+    L.append("s_cmp_lt_i32 s93, 0")
+    L.append("s_cbranch_scc1 .LFA_DONE%=")
+    L.append("s_sub_u32 s96, s93, %[trip0]")
+    L.append("s_xor_b32 s96, s96, 7")
+    L.append("s_bitset1_b32 %[w], s96")
     L.append(".LFA_DONE%=:")
     L.append("s_waitcnt lgkmcnt(0)")          # nothing of ours may still be in flight outside
     return L
@@ -214,14 +279,15 @@ def written_registers(lines):
     return sorted(regs)
 
 
-def emit(name, K, trace):
-    lines = gen_loop(K, trace)
+def emit(name, K, trace, kind):
+    lines = group_loop(K, trace) if kind == "group" else sel_loop(K, trace)
     probe = []
-    phase(probe, K, trace, 0, 0)
-    phase(probe, K, trace, 1, 1)
-    valu = sum(1 for l in probe if l.startswith("v_")) + 3   # + compare (2 slots) and address increment
-    out = [f"// {name}: {'trace' if trace else 'primary'} loop, {K} ray(s) per lane, {valu} VALU instructions per "
-           f"trip of {2 * NB} spheres when nothing is queued"]
+    phase(probe, K, trace, 0, 0, ball=(kind == "group"))
+    phase(probe, K, trace, 1, 1, ball=(kind == "group"))
+    valu = sum(1 for l in probe if l.startswith("v_")) + (2 if kind == "group" else 3)
+    what = "ball" if kind == "group" else "sphere"
+    out = [f"// {name}: {kind} loop, {'shared origin' if trace else 'precomputed -c'}, {K} ray(s) per lane, "
+           f"~{valu} VALU instructions per trip of {2 * NB} {what}s when nothing is queued"]
     out.append(f"#define {name}_VALU {valu}")
     out.append(f"#define {name}_ASM \\")
     for l in lines:
@@ -231,7 +297,8 @@ def emit(name, K, trace):
     regs = written_registers(lines)
     assert not (set(regs) & inputs), "the loop must not write its pinned inputs"
     cl = ", ".join(f'"v{r}"' for r in regs)
-    out.append(f"#define {name}_CLOBBERS {cl}, \"s97\", \"s98\", \"s99\", \"vcc\", \"scc\", \"memory\"")
+    sregs = ", ".join(f'"s{r}"' for r in range(93, 100))
+    out.append(f"#define {name}_CLOBBERS {cl}, {sregs}, \"vcc\", \"scc\", \"memory\"")
     return out
 
 
@@ -247,13 +314,17 @@ def main():
     out.append(f'#define FA_LANE "{{v[{LANE}:{LANE + 3}]}}"   // (Bx, By, Bz, C0), trace loops')
     out.append(f"#define FA_QUEUE_STRIDE {QSTRIDE}   // bytes between consecutive queue slots of one thread")
     out.append(f"#define FA_BATCH {NB}")
-    out.append(f"#define FA_TRIP {2 * NB}   // spheres per loop trip; the loop is entered at multiples of it")
-    out.append(f"#define FA_LDS_SLACK {NB}   // never-pass entries required behind the last batch")
+    out.append(f"#define FA_TRIP {2 * NB}   // entries per trip = spheres per bounding ball")
+    out.append(f"#define FA_LDS_SLACK {NB}   // entries a GROUP loop reads behind the last trip")
     out.append("")
-    out += emit("FA_PRIMARY4", 4, False)
+    out += emit("FA_PGROUP4", 4, False, "group")
+    out.append("")
+    out += emit("FA_PSEL4", 4, False, "sel")
     out.append("")
     for K in range(1, 6):
-        out += emit(f"FA_TRACE{K}", K, True)
+        out += emit(f"FA_GROUP{K}", K, True, "group")
+        out.append("")
+        out += emit(f"FA_SEL{K}", K, True, "sel")
         out.append("")
     with open(path, "w") as f:
         f.write("\n".join(out))
