@@ -452,13 +452,14 @@ __device__ __forceinline__ void fa_group(int &i, unsigned &addr, unsigned &qaddr
 }
 
 template <int K, bool TRACE>
-__device__ __forceinline__ void fa_sel(unsigned &w, unsigned &qaddr, const f4raw (&rq)[5], const f4raw lane,
-                                       const int trip0, const unsigned addr0, const unsigned qlim)
+__device__ __forceinline__ void fa_sel(unsigned long long &wlo, unsigned long long &whi, int &trip0, unsigned &qaddr,
+                                       const f4raw (&rq)[5], const f4raw lane, const unsigned addr0,
+                                       const unsigned qlim)
 {
-#define FA_RUN(NAME, ...)                                                                   \
-    asm volatile(NAME##_ASM                                                                 \
-                 : [w] "+s"(w), [qaddr] "+v"(qaddr)                                         \
-                 : __VA_ARGS__, [trip0] "s"(trip0), [addr0] "s"(addr0), [qlim] "s"(qlim)    \
+#define FA_RUN(NAME, ...)                                                                    \
+    asm volatile(NAME##_ASM                                                                  \
+                 : [wlo] "+s"(wlo), [whi] "+s"(whi), [trip0] "+s"(trip0), [qaddr] "+v"(qaddr) \
+                 : __VA_ARGS__, [addr0] "s"(addr0), [qlim] "s"(qlim)                          \
                  : NAME##_CLOBBERS)
     if constexpr (!TRACE) {
         FA_RUN(FA_PSEL4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]));
@@ -475,26 +476,26 @@ __device__ __forceinline__ void fa_sel(unsigned &w, unsigned &qaddr, const f4raw
 }
 
 // One staged chunk of `cnt` spheres (a multiple of RT_SPH_PAD) for K rays per lane.
-// exact(li) is called, per lane, for every sphere li of the chunk the lane's rays could hit;
-// the order of the calls is not the spheres' host order.  Every lane of the wave must be
-// active.
+// exact(sphere, host index) is called, per lane, for every sphere of the chunk the lane's
+// rays could hit, with the sphere's {centre, r*r} and host primitive index read from
+// sph / orig (the chunk's part of DevScene::sph / sph_orig; the next candidate's data is
+// fetched while the current one is evaluated).  The order of the calls is not the spheres'
+// host order.  Every lane of the wave must be active.
 template <int K, bool TRACE, class Exact>
 __device__ __forceinline__ void walk_chunk(const float4 *lds, const float4 *ldg, int *cand, const int cnt,
-                                           const f4raw (&rq)[5], const f4raw lane_g, const f4raw lane,
-                                           Exact &&exact)
+                                           const float4 *sph, const int *orig, const f4raw (&rq)[5],
+                                           const f4raw lane_g, const f4raw lane, int &candidates, Exact &&exact)
 {
     const unsigned q0 = lds_offset(cand) + 4u * threadIdx.x;
     const unsigned qlim = lds_offset(cand) + QUEUE_SLOTS * FA_QUEUE_STRIDE;
     const int ngroups = cnt / RT_GROUP, ntrips = ngroups / FA_TRIP;
-#if !defined(RT_EXPERIMENT) || RT_EXPERIMENT < 3
     {
         int i = 0;
         unsigned addr = lds_offset(ldg), qaddr = q0;
         fa_group<K, TRACE>(i, addr, qaddr, rq, lane_g, ngroups);
     }
-#endif
     // Pass bits of 32 groups per word (bit 8t + b = group 8(4*word + t) + 7 - b), wave-wide.
-    static_assert(GRP_WORDS == 4, "four bitmap words per chunk");
+    static_assert(GRP_WORDS == 4, "the bitmap of a chunk is two 64-bit halves");
     unsigned words[GRP_WORDS];
 #pragma unroll
     for (int wd = 0; wd < GRP_WORDS; wd++) {
@@ -506,34 +507,37 @@ __device__ __forceinline__ void walk_chunk(const float4 *lds, const float4 *ldg,
         }
         words[wd] = wave_or(bits);
     }
-    // One copy of the SEL loop and of the exact evaluation in the code: the words rotate
-    // through w0 (the kernels' instruction footprint matters, see k_trace_levels).
-    unsigned w0 = words[0], w1 = words[1], w2 = words[2], w3 = words[3];
-#if defined(RT_EXPERIMENT) && RT_EXPERIMENT >= 2
-    w0 = w1 = w2 = w3 = 0u;
-#endif
+    unsigned long long wlo = (unsigned long long)words[0] | ((unsigned long long)words[1] << 32);
+    unsigned long long whi = (unsigned long long)words[2] | ((unsigned long long)words[3] << 32);
     int trip0 = 0;
 #pragma clang loop unroll(disable)
-    while ((w0 | w1 | w2 | w3) != 0u) {
-        if (w0 != 0u) {
-            unsigned qaddr = q0;
-            fa_sel<K, TRACE>(w0, qaddr, rq, lane, trip0, lds_offset(lds), qlim);
-            CandidateWalk walk(cand, (int)((qaddr - q0) / FA_QUEUE_STRIDE));
-#pragma clang loop unroll(disable)
-            for (;;) {
-                const int li = walk.next();
-                if (__ballot(li >= 0) == 0ull) break;
-#if !defined(RT_EXPERIMENT) || RT_EXPERIMENT < 1
-                if (li >= 0) exact(li);
-#endif
-            }
+    while ((wlo | whi) != 0ull) {
+        unsigned qaddr = q0;
+        fa_sel<K, TRACE>(wlo, whi, trip0, qaddr, rq, lane, lds_offset(lds), qlim);
+        CandidateWalk walk(cand, (int)((qaddr - q0) / FA_QUEUE_STRIDE));
+        int li = walk.next();
+        float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
+        int og = 0;
+        if (li >= 0) {
+            sp = sph[li];
+            og = orig[li];
         }
-        if (w0 == 0u) {
-            w0 = w1;
-            w1 = w2;
-            w2 = w3;
-            w3 = 0u;
-            trip0 += 32;
+#pragma clang loop unroll(disable)
+        while (__ballot(li >= 0) != 0ull) {
+            const int ln = li >= 0 ? walk.next() : -1;
+            float4 spn = sp;
+            int ogn = og;
+            if (ln >= 0) {
+                spn = sph[ln];
+                ogn = orig[ln];
+            }
+            if (li >= 0) {
+                candidates++;
+                exact(sp, og);
+            }
+            li = ln;
+            sp = spn;
+            og = ogn;
         }
     }
 }
@@ -614,22 +618,18 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
             // Exact evaluation of a candidate: objects.cs:112-121 literally; among equal
             // distances the lower host index wins, as the strict `<` of MyApplication.cs:361
             // decides when the primitives are scanned in host order.
-            walk_chunk<PRIM_PX, false>(lds, ldg, cand, cnt, rq, fo.lane_g, fo.lane, [&](int li) {
-                candidates++;
-                const float4 sp = s.sph[base + li];
+            walk_chunk<PRIM_PX, false>(lds, ldg, cand, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_g, fo.lane,
+                                       candidates, [&](const float4 sp, const int orig) {
                 const f3 op = sub3(o, xyz(sp));
                 const float c = dot3(op, op) - sp.w;
-                int orig = -1;
 #pragma unroll
                 for (int k = 0; k < PRIM_PX; k++) {
                     const float xx = dot3(d[k], op);
                     float t;
-                    if (sphere_maybe(xx, a[k] * c) && sphere_root(xx, c, a[k], t) && t > RT_EPS && t <= best_t[k]) {
-                        if (orig < 0) orig = s.sph_orig[base + li];
-                        if (t < best_t[k] || orig < best_prim[k]) {
-                            best_t[k] = t;
-                            best_prim[k] = orig;
-                        }
+                    if (sphere_maybe(xx, a[k] * c) && sphere_root(xx, c, a[k], t) && t > RT_EPS &&
+                        (t < best_t[k] || (t == best_t[k] && orig < best_prim[k]))) {
+                        best_t[k] = t;
+                        best_prim[k] = orig;
                     }
                 }
             });
@@ -716,31 +716,25 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, float4 
         // Closest hit: among equal distances the lower host index wins (MyApplication.cs:361);
         // shadow rays: the lowest host index among the occluders is the one the reference
         // meets first (MyApplication.cs:373-378).
-        walk_chunk<NR, true>(lds, ldg, cand, cnt, rq, fo.lane_g, fo.lane, [&](int li) {
-            candidates++;
-            const float4 sp = s.sph[base + li];
+        walk_chunk<NR, true>(lds, ldg, cand, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_g, fo.lane, candidates,
+                             [&](const float4 sp, const int orig) {
             const f3 op = sub3(o, xyz(sp));
             const float c = dot3(op, op) - sp.w;
-            int orig = -1;
             float t;
             if (SEC) {
                 const float x = dot3(r.sec_d, op);
-                if (sphere_maybe(x, r.sec_a * c) && sphere_root(x, c, r.sec_a, t) && t > RT_EPS && t <= best_t) {
-                    orig = s.sph_orig[base + li];
-                    if (t < best_t || orig < best_prim) {
-                        best_t = t;
-                        best_prim = orig;
-                    }
+                if (sphere_maybe(x, r.sec_a * c) && sphere_root(x, c, r.sec_a, t) && t > RT_EPS &&
+                    (t < best_t || (t == best_t && orig < best_prim))) {
+                    best_t = t;
+                    best_prim = orig;
                 }
             }
 #pragma unroll
             for (int l = 0; l < LC; l++) {
                 const float x = dot3(r.sh_d[l], op);
                 if (sphere_maybe(x, r.sh_a[l] * c) && sphere_root(x, c, r.sh_a[l], t) && t > RT_EPS &&
-                    t < r.sh_dist[l]) {
-                    if (orig < 0) orig = s.sph_orig[base + li];
+                    t < r.sh_dist[l])
                     r.sh_first[l] = min(r.sh_first[l], orig);
-                }
             }
         });
     }

@@ -30,7 +30,7 @@ Register plan (VGPR numbers; b0..b3 = bank):
                                    2 and SA the sphere's combined verdict word
       i < 6:  TA(i) b0, TB(i) b1   temporaries of ray chain i
       4..6 :  VT(2(i-4)) b2, VT(2(i-4)+1) b3   v1 of ray chain j (GROUP loops)
-  s[98:99]          saved exec mask during the append, s93..s97 scratch
+  s[98:99]          saved exec mask during the append, s88..s97 scratch
 
 A trip handles 8 consecutive entries of the staged array in two batches of 4, the two register
 sets in ping-pong (the LDS reads of one batch fly while the other is computed).  The sign bits
@@ -43,14 +43,15 @@ bit 7-m, 1 = cannot hit).  Two kinds of loop are generated:
       The verdict is "the ray's half-line meets the ball":
           v1 = fma(x', x', -c'');  reject = (sign(v1) | sign(x')) & sign(c'')
       Behind the last trip there must be 4 more entries (the loop reads one batch ahead).
-  SEL loops    run the sphere trips named by a wave-uniform 32-bit bitmap w (bit b = trip
-      trip0 + (b ^ 7)), lowest bit first; the first batch of the next selected trip is
+  SEL loops    run the sphere trips named by a wave-uniform bitmap of two 64-bit halves (bit b
+      of the low half = trip trip0 + (b ^ 7); the high half follows 64 trips later), lowest
+      bit first; the first batch of the next selected trip is
       fetched while the second batch of the current one is computed.  Lanes with a clear
       mask bit append the word (first sphere index << 8 | mask) to their queue, tested with
       ONE compare and branch per trip, and the loop goes on; the C++ caller runs the exact
       evaluation over each lane's queue afterwards.  The loop leaves early when some lane's
-      queue is full (its qaddr has reached qlim), with the trips not yet run left in w; the
-      caller drains the queues and re-enters.
+      queue is full (its qaddr has reached qlim), with the trips not yet run left in the
+      bitmap; the caller drains the queues and re-enters.
 """
 import os
 
@@ -197,10 +198,23 @@ def group_loop(K, trace):
     return L
 
 
-def next_trip(L, dst):
-    """Takes the lowest set bit of the bitmap: dst = its trip, v24 = the trip's LDS address."""
-    L.append("s_ff1_i32_b32 s96, %[w]")
-    L.append("s_bitset0_b32 %[w], s96")
+def rotate(L, tag):
+    """The bitmap is two 64-bit halves: when the low half is used up the high half takes its
+    place (trip0 moves on by 64)."""
+    L.append("s_cmp_eq_u64 %[wlo], 0")
+    L.append(f"s_cbranch_scc0 .LFA_{tag}%=")
+    L.append("s_mov_b64 %[wlo], %[whi]")
+    L.append("s_mov_b64 %[whi], 0")
+    L.append("s_add_u32 %[trip0], %[trip0], 64")
+    L.append(f".LFA_{tag}%=:")
+
+
+def next_trip(L, dst, tag):
+    """Takes the lowest set bit of the bitmap (which must not be empty): dst = its trip,
+    v24 = the trip's LDS address."""
+    rotate(L, tag)
+    L.append("s_ff1_i32_b64 s96, %[wlo]")
+    L.append("s_bitset0_b64 %[wlo], s96")
     L.append(f"s_xor_b32 {dst}, s96, 7")
     L.append(f"s_add_u32 {dst}, {dst}, %[trip0]")
     L.append(f"s_lshl_b32 s94, {dst}, {(2 * NB * 16).bit_length() - 1}")
@@ -215,18 +229,20 @@ def sel_loads(L, which, byte_offset):
 
 
 def sel_loop(K, trace):
-    """SEL loop: the sphere trips named by the bitmap w; s95 = current trip, s93 = next or -1."""
+    """SEL loop: the sphere trips named by the bitmap; s95 = current trip, s93 = next or -1."""
     L = []
-    next_trip(L, "s95")
+    L.append("s_waitcnt lgkmcnt(0)")          # the in-order counting below starts from zero
+    next_trip(L, "s95", "R0")
     sel_loads(L, 0, 0)
     L.append(".LFA_LOOP%=:")
     sel_loads(L, 1, 16 * NB)
     L.append(f"s_waitcnt lgkmcnt({NB})")      # LDS returns in order: the first batch has arrived
     phase(L, K, trace, 0, 0)
     L.append("s_mov_b32 s93, -1")
-    L.append("s_cmp_eq_u32 %[w], 0")
+    L.append("s_or_b64 s[88:89], %[wlo], %[whi]")
+    L.append("s_cmp_eq_u64 s[88:89], 0")
     L.append("s_cbranch_scc1 .LFA_LAST%=")
-    next_trip(L, "s93")
+    next_trip(L, "s93", "R1")
     L.append("s_waitcnt lgkmcnt(0)")
     sel_loads(L, 0, 0)                         # the next trip's first batch flies during phase 1
     L.append("s_branch .LFA_PH1%=")
@@ -257,7 +273,7 @@ def sel_loop(K, trace):
     L.append("s_cbranch_scc1 .LFA_DONE%=")
     L.append("s_sub_u32 s96, s93, %[trip0]")
     L.append("s_xor_b32 s96, s96, 7")
-    L.append("s_bitset1_b32 %[w], s96")
+    L.append("s_bitset1_b64 %[wlo], s96")
     L.append(".LFA_DONE%=:")
     L.append("s_waitcnt lgkmcnt(0)")          # nothing of ours may still be in flight outside
     return L
@@ -297,7 +313,7 @@ def emit(name, K, trace, kind):
     regs = written_registers(lines)
     assert not (set(regs) & inputs), "the loop must not write its pinned inputs"
     cl = ", ".join(f'"v{r}"' for r in regs)
-    sregs = ", ".join(f'"s{r}"' for r in range(93, 100))
+    sregs = ", ".join(f'"s{r}"' for r in range(88, 100))
     out.append(f"#define {name}_CLOBBERS {cl}, {sregs}, \"vcc\", \"scc\", \"memory\"")
     return out
 
