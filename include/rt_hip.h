@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RT_API_VERSION 1
+#define RT_API_VERSION 2
 
 /* Primitive type codes — the reference's own flatten uses exactly these
  * (MyApplication.cs:161,166,173). */
@@ -123,6 +123,14 @@ typedef struct rt_stats {
     uint64_t triangle_tests;
     uint64_t exact_candidates; /* (ray origin, sphere) pairs the conservative sphere filter
                                   passed on to the exact Intersect code: a cost figure      */
+    uint64_t filter_ray_tests; /* (ray, sphere or bounding ball) pairs the filter evaluated:
+                                  what the kernels executed in place of sphere_tests; groups
+                                  of spheres whose bounding ball no ray of a wave can meet
+                                  are skipped                                               */
+    uint64_t filter_origin_terms; /* (ray origin, sphere or ball) pairs for which the filter's
+                                  per-origin term was formed (secondary and shadow rays)    */
+    uint64_t primary_filter_ray_tests; /* the primary rays' share of filter_ray_tests ...   */
+    uint64_t primary_exact_candidates; /* ... and of exact_candidates                        */
     double   kernel_ms;
     double   primary_ms;
     double   trace_ms;

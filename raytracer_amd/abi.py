@@ -73,6 +73,10 @@ class rt_stats(C.Structure):
         ("plane_tests", C.c_uint64),
         ("triangle_tests", C.c_uint64),
         ("exact_candidates", C.c_uint64),
+        ("filter_ray_tests", C.c_uint64),
+        ("filter_origin_terms", C.c_uint64),
+        ("primary_filter_ray_tests", C.c_uint64),
+        ("primary_exact_candidates", C.c_uint64),
         ("kernel_ms", C.c_double),
         ("primary_ms", C.c_double),
         ("trace_ms", C.c_double),

@@ -444,7 +444,8 @@ int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
         HIP_TRY(ctx, hipMalloc((void **)&d.frame.cnt, 2 * (size_t)(levels + 1) * sizeof(int)));
         d.cap_levels = levels + 1;
     }
-    if (!d.frame.counters) HIP_TRY(ctx, hipMalloc((void **)&d.frame.counters, sizeof(DevCounters)));
+    if (!d.frame.counters)
+        HIP_TRY(ctx, hipMalloc((void **)&d.frame.counters, RT_COUNTER_SLOTS * sizeof(DevCounters)));
     if (!d.frame.sched) HIP_TRY(ctx, hipMalloc((void **)&d.frame.sched, sizeof(DevSched)));
     d.frame.P = P;
     d.frame.slots = (int)slots;
@@ -500,11 +501,11 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     const DevCamera dc = make_camera(cam, w, h, y0, y1);
     const DevFrame &f = d.frame;
     HIP_TRY(ctx, hipMemsetAsync(f.cnt, 0, 2 * (size_t)(max_depth + 2) * sizeof(int), stream));
-    HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, sizeof(DevCounters), stream));
+    HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, RT_COUNTER_SLOTS * sizeof(DevCounters), stream));
     HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, sizeof(DevSched), stream));
     d.timed = ctx->profiling && stream == d.stream;
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
-    const int blocks = std::max(1, std::min((P + 255) / 256, d.num_cus * 8));
+    const int blocks = std::max(1, std::min({(P + 255) / 256, d.num_cus * 8, RT_COUNTER_SLOTS}));
     rtk_setup_camera(d.scene, dc, d.sph_cam, d.grp_cam, stream);
     rtk_primary(d.scene, dc, f, dev_pixels, blocks, stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[1], stream));
@@ -523,7 +524,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
             d.resident_nl = d.scene.nl;
         }
         const int tiles0 = (P + 255) / 256;
-        rtk_trace_levels(d.scene, f, std::max(1, std::min(2 * tiles0, d.resident_blocks)), stream);
+        rtk_trace_levels(d.scene, f, std::max(1, std::min({2 * tiles0, d.resident_blocks, RT_COUNTER_SLOTS})), stream);
     }
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[2], stream));
     for (int k = max_depth; k >= 0; k--) rtk_shade_level(d.scene, f, k, dev_pixels, blocks, stream);
@@ -803,7 +804,16 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out)
         std::vector<int> cnt(2 * (size_t)(d.last_depth + 2));
         DevCounters c{};
         HIP_TRY(ctx, hipMemcpy(cnt.data(), d.frame.cnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(&c, d.frame.counters, sizeof c, hipMemcpyDeviceToHost));
+        {
+            static_assert(sizeof(DevCounters) % sizeof(uint64_t) == 0, "DevCounters is an array of 64-bit counts");
+            constexpr size_t words = sizeof(DevCounters) / sizeof(uint64_t);
+            std::vector<uint64_t> slots(RT_COUNTER_SLOTS * words);
+            HIP_TRY(ctx, hipMemcpy(slots.data(), d.frame.counters, slots.size() * sizeof(uint64_t),
+                                   hipMemcpyDeviceToHost));
+            uint64_t sum[words] = {};
+            for (size_t i = 0; i < slots.size(); i++) sum[i % words] += slots[i];
+            memcpy(&c, sum, sizeof c);
+        }
         int rc = check_schedule(ctx, d);
         if (rc != RT_OK) return rc;
         uint64_t hits = 0, secondary = 0;
@@ -820,6 +830,10 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out)
         out->plane_tests += c.plane_tests + P * (uint64_t)d.scene.np;
         out->triangle_tests += c.triangle_tests + P * (uint64_t)d.scene.nt;
         out->exact_candidates += c.exact_candidates;
+        out->filter_ray_tests += c.filter_ray_tests;
+        out->filter_origin_terms += c.filter_origin_terms;
+        out->primary_filter_ray_tests += c.primary_filter_ray_tests;
+        out->primary_exact_candidates += c.primary_exact_candidates;
         if (d.timed) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, d.ev[0], d.ev[3]) == hipSuccess) kernel_ms = std::max(kernel_ms, (double)ms);

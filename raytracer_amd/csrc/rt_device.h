@@ -84,12 +84,21 @@ struct DevCamera {
     int row_begin, row_end;
 };
 
-// Device-side counters of one render call.
+// Device-side counters of one render call.  DevFrame::counters holds RT_COUNTER_SLOTS of
+// them: every workgroup adds its totals to the slot of its blockIdx.x with plain loads and
+// stores (launches are stream-ordered and no grid is larger than RT_COUNTER_SLOTS), and the
+// host sums the slots when statistics are asked for.  One counter word shared by the whole
+// grid would take only ~90 atomics per microsecond, a visible tail on a 2 ms frame.
+#define RT_COUNTER_SLOTS 4096
 struct DevCounters {
     unsigned long long sphere_tests;
     unsigned long long plane_tests;
     unsigned long long triangle_tests;
     unsigned long long exact_candidates;   // (ray origin, sphere) pairs evaluated exactly
+    unsigned long long filter_ray_tests;   // (ray, sphere or ball) pairs the filter evaluated
+    unsigned long long filter_origin_terms;   // (origin, sphere or ball) per-origin terms formed
+    unsigned long long primary_filter_ray_tests;   // the primary kernel's share of filter_ray_tests
+    unsigned long long primary_exact_candidates;   // ... and of exact_candidates
 };
 
 // Tile schedule of k_trace_levels (rt_kernels.hip), zeroed before every render call.

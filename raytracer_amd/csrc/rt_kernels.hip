@@ -170,6 +170,27 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
+// Adds a workgroup's totals to its slot of DevFrame::counters (rt_device.h).  v[i] is the
+// calling wave's total of counter word i (read from lane 0); sh is a __shared__ array of
+// COUNTER_WORDS words.  Every thread of the workgroup must call it (barriers inside).
+#define COUNTER_WORDS (int)(sizeof(DevCounters) / sizeof(unsigned long long))
+__device__ __forceinline__ void flush_counters(const DevFrame &f, unsigned long long *sh,
+                                               const unsigned long long (&v)[COUNTER_WORDS])
+{
+    if (threadIdx.x < COUNTER_WORDS) sh[threadIdx.x] = 0ull;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < COUNTER_WORDS; i++)
+            if (v[i]) atomicAdd(&sh[i], v[i]);
+    }
+    __syncthreads();
+    if (threadIdx.x < COUNTER_WORDS && sh[threadIdx.x]) {
+        unsigned long long *slot = reinterpret_cast<unsigned long long *>(&f.counters[blockIdx.x % RT_COUNTER_SLOTS]);
+        slot[threadIdx.x] += sh[threadIdx.x];
+    }
+}
+
 __device__ __forceinline__ bool material_specular_nonzero(const DevScene &s, int prim)
 {
     return cload(s.mat, 3 * prim).w != 0.0f;
@@ -480,20 +501,25 @@ __device__ __forceinline__ void fa_sel(unsigned long long &wlo, unsigned long lo
 // rays could hit, with the sphere's {centre, r*r} and host primitive index read from
 // sph / orig (the chunk's part of DevScene::sph / sph_orig; the next candidate's data is
 // fetched while the current one is evaluated).  The order of the calls is not the spheres'
-// host order.  Every lane of the wave must be active.
+// host order.  candidates counts the calls, trips the trips of FA_TRIP balls or spheres the
+// filter loops ran.  Every lane of the wave must be active.
 template <int K, bool TRACE, class Exact>
 __device__ __forceinline__ void walk_chunk(const float4 *lds, const float4 *ldg, int *cand, const int cnt,
                                            const float4 *sph, const int *orig, const f4raw (&rq)[5],
-                                           const f4raw lane_g, const f4raw lane, int &candidates, Exact &&exact)
+                                           const f4raw lane_g, const f4raw lane, int &candidates, int &trips,
+                                           Exact &&exact)
 {
     const unsigned q0 = lds_offset(cand) + 4u * threadIdx.x;
     const unsigned qlim = lds_offset(cand) + QUEUE_SLOTS * FA_QUEUE_STRIDE;
     const int ngroups = cnt / RT_GROUP, ntrips = ngroups / FA_TRIP;
+#if !defined(RT_EXPERIMENT) || RT_EXPERIMENT < 3   // RT_EXPERIMENT: timing builds only, wrong images
     {
         int i = 0;
         unsigned addr = lds_offset(ldg), qaddr = q0;
         fa_group<K, TRACE>(i, addr, qaddr, rq, lane_g, ngroups);
+        trips += ntrips;
     }
+#endif
     // Pass bits of 32 groups per word (bit 8t + b = group 8(4*word + t) + 7 - b), wave-wide.
     static_assert(GRP_WORDS == 4, "the bitmap of a chunk is two 64-bit halves");
     unsigned words[GRP_WORDS];
@@ -510,10 +536,15 @@ __device__ __forceinline__ void walk_chunk(const float4 *lds, const float4 *ldg,
     unsigned long long wlo = (unsigned long long)words[0] | ((unsigned long long)words[1] << 32);
     unsigned long long whi = (unsigned long long)words[2] | ((unsigned long long)words[3] << 32);
     int trip0 = 0;
+#if defined(RT_EXPERIMENT) && RT_EXPERIMENT >= 2
+    wlo = whi = 0ull;
+#endif
 #pragma clang loop unroll(disable)
     while ((wlo | whi) != 0ull) {
         unsigned qaddr = q0;
+        trips += __popcll(wlo) + __popcll(whi);
         fa_sel<K, TRACE>(wlo, whi, trip0, qaddr, rq, lane, lds_offset(lds), qlim);
+        trips -= __popcll(wlo) + __popcll(whi);   // what a full queue left for the next call
         CandidateWalk walk(cand, (int)((qaddr - q0) / FA_QUEUE_STRIDE));
         int li = walk.next();
         float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -533,7 +564,9 @@ __device__ __forceinline__ void walk_chunk(const float4 *lds, const float4 *ldg,
             }
             if (li >= 0) {
                 candidates++;
+#if !defined(RT_EXPERIMENT) || RT_EXPERIMENT < 1
                 exact(sp, og);
+#endif
             }
             li = ln;
             sp = spn;
@@ -570,6 +603,7 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
     __shared__ float4 ldg[GRP_LDS_ENTRIES];
     __shared__ int cand[QUEUE_INTS];
     __shared__ int blk[12];
+    __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rows = cam.row_end - cam.row_begin;
     const int tiles_x = (cam.width + 31) >> 5, tiles_y = (rows + 31) >> 5;
@@ -582,7 +616,7 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
         stage_chunk(lds, ldg, s.sph_cam, s.grp_cam, 0, nsp);
         __syncthreads();
     }
-    int candidates = 0;
+    int candidates = 0, trips = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = tile / tiles_x;
         const int x0 = tx * 32 + (wave & 1) * 16 + (lane & 7) * 2;
@@ -619,7 +653,7 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
             // distances the lower host index wins, as the strict `<` of MyApplication.cs:361
             // decides when the primitives are scanned in host order.
             walk_chunk<PRIM_PX, false>(lds, ldg, cand, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_g, fo.lane,
-                                       candidates, [&](const float4 sp, const int orig) {
+                                       candidates, trips, [&](const float4 sp, const int orig) {
                 const f3 op = sub3(o, xyz(sp));
                 const float c = dot3(op, op) - sp.w;
 #pragma unroll
@@ -665,8 +699,12 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
         }
         push_records<PRIM_PX>(f, s, 0, blk, rec_valid, rec_prim, rec_hit, d, rec_parent);
     }
-    candidates = wave_sum(candidates);
-    if (lane == 0 && candidates) atomicAdd(&f.counters->exact_candidates, (unsigned long long)candidates);
+    // Counter words in the order of DevCounters; trips is wave-uniform: every lane ran them,
+    // on PRIM_PX rays each.
+    const unsigned long long cand_total = (unsigned long long)wave_sum(candidates);
+    const unsigned long long tests = (unsigned long long)trips * (64ull * FA_TRIP * PRIM_PX);
+    const unsigned long long v[COUNTER_WORDS] = {0ull, 0ull, 0ull, cand_total, tests, 0ull, tests, cand_total};
+    flush_counters(f, cnt_sh, v);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -676,6 +714,14 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
 // the filter's per-sphere term is formed once per sphere and shared by the record's NR rays:
 // a sphere costs 4 + 4*NR full-rate instructions per lane plus one per two or three rays.
 // ---------------------------------------------------------------------------------------
+// Per-lane work counters of a kernel.
+struct TestCount {
+    int sph, pl, tri;
+    int exact;        // (record, sphere) pairs this lane evaluated exactly
+    int filt_terms;   // spheres and balls this lane formed the filter's per-origin term for
+    int filt_rays;    // (ray, sphere or ball) pairs this lane's filter evaluated
+};
+
 template <int LC, bool SEC>
 struct Rays {
     f3 sh_d[LC > 0 ? LC : 1];
@@ -689,7 +735,7 @@ struct Rays {
 
 template <int LC, bool SEC>
 __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, float4 *ldg, int *cand, const bool single,
-                                         const f3 o, Rays<LC, SEC> &r, int &candidates)
+                                         const f3 o, Rays<LC, SEC> &r, TestCount &tc)
 {
     constexpr int NR = LC + (SEC ? 1 : 0);
     static_assert(NR >= 1 && NR <= 5, "one filter loop per ray count 1..5");
@@ -704,6 +750,7 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, float4 
 
     float best_t = RT_FLT_MAX;
     int best_prim = INT_MAX;   // host index of the closest sphere so far
+    int trips = 0;
     const int nsp = s.ns_padded;
     for (int base = 0; base < nsp; base += SPH_CHUNK) {
         const int cnt = min(SPH_CHUNK, nsp - base);
@@ -716,8 +763,8 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, float4 
         // Closest hit: among equal distances the lower host index wins (MyApplication.cs:361);
         // shadow rays: the lowest host index among the occluders is the one the reference
         // meets first (MyApplication.cs:373-378).
-        walk_chunk<NR, true>(lds, ldg, cand, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_g, fo.lane, candidates,
-                             [&](const float4 sp, const int orig) {
+        walk_chunk<NR, true>(lds, ldg, cand, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_g, fo.lane, tc.exact,
+                             trips, [&](const float4 sp, const int orig) {
             const f3 op = sub3(o, xyz(sp));
             const float c = dot3(op, op) - sp.w;
             float t;
@@ -738,6 +785,8 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, float4 
             }
         });
     }
+    tc.filt_terms += trips * FA_TRIP;
+    tc.filt_rays += trips * FA_TRIP * NR;
     if (SEC) {
         r.sec.t = best_t;
         r.sec.prim = best_prim;
@@ -784,10 +833,6 @@ __device__ __forceinline__ f3 record_normal(const DevScene &s, int prim, int typ
     return xyz(g);
 }
 
-struct TestCount {
-    int sph, pl, tri;
-    int exact;   // (record, sphere) pairs this lane evaluated exactly
-};
 
 // One chunk of LC lights (plus the reflection ray when SEC) for one record.
 template <int LC, bool SEC>
@@ -812,7 +857,7 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, floa
         r.sec.t = RT_FLT_MAX;
         r.sec.prim = INT_MAX;
     }
-    traverse<LC, SEC>(s, lds, ldg, cand, single, hit, r, tc.exact);
+    traverse<LC, SEC>(s, lds, ldg, cand, single, hit, r, tc);
 #pragma unroll
     for (int l = 0; l < LC; l++) {
         const bool occluded = r.sh_first[l] != INT_MAX;
@@ -855,7 +900,7 @@ __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f,
 
     Closest sec = {RT_FLT_MAX, INT_MAX};
     f3 sec_dir = mk3(0.0f, 0.0f, 0.0f);
-    TestCount ltc = {0, 0, 0, 0};
+    TestCount ltc = {0, 0, 0, 0, 0, 0};
     uint32_t word = 0;
     int l0 = 0;
     bool first = true;
@@ -890,6 +935,8 @@ __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f,
         tc.tri += ltc.tri;
         tc.exact += ltc.exact;
     }
+    tc.filt_terms += ltc.filt_terms;   // inactive lanes run the loops too
+    tc.filt_rays += ltc.filt_rays;
     if (SEC) {
         const bool child = active && sec.prim != INT_MAX;
         const f3 hit2 = add3(hit, scale3(sec_dir, sec.t));   // objects.cs:123,166,263
@@ -901,15 +948,15 @@ __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f,
     }
 }
 
-__device__ __forceinline__ void flush_test_counts(const DevFrame &f, const TestCount &tc)
+__device__ __forceinline__ void flush_test_counts(const DevFrame &f, unsigned long long *cnt_sh, const TestCount &tc)
 {
+    static_assert(COUNTER_WORDS == 8, "the initialiser below follows DevCounters word for word");
     const int ws = wave_sum(tc.sph), wp = wave_sum(tc.pl), wt = wave_sum(tc.tri), we = wave_sum(tc.exact);
-    if ((threadIdx.x & 63) == 0) {
-        if (ws) atomicAdd(&f.counters->sphere_tests, (unsigned long long)ws);
-        if (wp) atomicAdd(&f.counters->plane_tests, (unsigned long long)wp);
-        if (wt) atomicAdd(&f.counters->triangle_tests, (unsigned long long)wt);
-        if (we) atomicAdd(&f.counters->exact_candidates, (unsigned long long)we);
-    }
+    // the filter counts are the same in every lane of the wave
+    const unsigned long long v[COUNTER_WORDS] = {(unsigned long long)ws, (unsigned long long)wp, (unsigned long long)wt,
+                                                 (unsigned long long)we, 64ull * (unsigned long long)tc.filt_rays,
+                                                 64ull * (unsigned long long)tc.filt_terms, 0ull, 0ull};
+    flush_counters(f, cnt_sh, v);
 }
 
 // One queue of one level per launch (the form a kernel trace can attribute time to; the
@@ -921,6 +968,7 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
     __shared__ float4 ldg[GRP_LDS_ENTRIES];
     __shared__ int cand[QUEUE_INTS];
     __shared__ int blk[12];
+    __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int n = SEC ? f.cnt[2 * level] : f.cnt[2 * level + 1];
     const int ntiles = (n + 255) >> 8;
     const bool single = s.ns_padded <= SPH_CHUNK;
@@ -928,11 +976,11 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
         stage_chunk(lds, ldg, s.sph_f, s.grp_f, 0, s.ns_padded);
         __syncthreads();
     }
-    TestCount tc = {0, 0, 0, 0};
+    TestCount tc = {0, 0, 0, 0, 0, 0};
     // Workgroup-uniform trip count: the sphere chunks are staged between barriers.
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
         trace_tile<SEC, LCMAX>(s, f, lds, ldg, cand, blk, single, level, tile, n, tc);
-    flush_test_counts(f, tc);
+    flush_test_counts(f, cnt_sh, tc);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -988,13 +1036,14 @@ k_trace_levels(DevScene s, DevFrame f)
     __shared__ float4 ldg[GRP_LDS_ENTRIES];
     __shared__ int cand[QUEUE_INTS];
     __shared__ int blk[12];
+    __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     __shared__ int job[4];
     __shared__ int lv_a[RT_DEV_MAX_LEVELS], lv_b[RT_DEV_MAX_LEVELS];   // record counts of the seen levels (thread 0)
     DevSched *const sc = f.sched;
     const int D = f.max_depth;
     const bool single = s.ns_padded <= SPH_CHUNK;
     bool staged = false;
-    TestCount tc = {0, 0, 0, 0};
+    TestCount tc = {0, 0, 0, 0, 0, 0};
     Taker tk = {-1, 0, false, 0u};
     for (;;) {
         if (threadIdx.x == 0) {
@@ -1078,7 +1127,7 @@ k_trace_levels(DevScene s, DevFrame f)
             trace_tile<false, LCMAX>(s, f, lds, ldg, cand, blk, single, lvl, tile, n, tc);
         }
     }
-    flush_test_counts(f, tc);
+    flush_test_counts(f, cnt_sh, tc);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -22,13 +22,13 @@ def test_library_exports_every_declared_symbol():
     lib = abi.load_library()
     for name in declared_functions():
         assert getattr(lib, name) is not None, name
-    assert lib.rt_api_version() == 1
+    assert lib.rt_api_version() == 2
 
 
 def test_struct_sizes_match_the_header_layout():
     assert ctypes.sizeof(abi.rt_camera) == 40
     assert ctypes.sizeof(abi.rt_scene) == 8 + 16 * 8
-    assert ctypes.sizeof(abi.rt_stats) == 8 * 8 + 6 * 8 + 8
+    assert ctypes.sizeof(abi.rt_stats) == 12 * 8 + 6 * 8 + 8
 
 
 def test_no_device_is_an_error_not_a_crash():
