@@ -1,5 +1,6 @@
-// filter_loop_bench.hip — runs generated filter loops (filter_asm.inc) alone on never-passing
-// data and reports cycles per VALU instruction, per occupancy.
+// filter_loop_bench.hip — runs generated GROUP loops (filter_asm.inc: the sequential walk over
+// an array of balls, same instruction mix and LDS traffic as the sphere trips) alone on
+// never-passing data and reports cycles per VALU instruction, per occupancy.
 // Build: hipcc --offload-arch=gfx950 -O3 -I raytracer_amd/csrc tools/filter_loop_bench.hip -o tools/filter_loop_bench
 //        (-DFA_INC='"other.inc"' to time an experimental variant of the generator's output)
 #include <hip/hip_runtime.h>
@@ -28,29 +29,29 @@ __global__ void __launch_bounds__(256) k(const float4 *sph, int reps, float *out
     int hits = 0;
     for (int r = 0; r < reps; r++) {
         int i = 0;
-        const int cnt = CH;
         unsigned addr = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char *)lds;
         const unsigned q0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char *)cand + 4u * threadIdx.x;
-        const unsigned qlim = q0 + 8 * 1024 + 1020;
         unsigned qaddr = q0;
-        while (i < cnt) {
-            if constexpr (LOOP == 0)
-                asm volatile(FA_PRIMARY4_ASM
-                             : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
-                             : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), [cnt] "s"(cnt), [qlim] "s"(qlim)
-                             : FA_PRIMARY4_CLOBBERS);
-            if constexpr (LOOP == 2)
-                asm volatile(FA_TRACE2_ASM
-                             : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
-                             : FA_DN0(r0), FA_DN1(r1), FA_LANE(lane), [cnt] "s"(cnt), [qlim] "s"(qlim)
-                             : FA_TRACE2_CLOBBERS);
-            if constexpr (LOOP == 3)
-                asm volatile(FA_TRACE3_ASM
-                             : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
-                             : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_LANE(lane), [cnt] "s"(cnt), [qlim] "s"(qlim)
-                             : FA_TRACE3_CLOBBERS);
-            hits += (int)(qaddr - q0);
+        // 16 trips per call: one queue slot per trip, as in the kernels
+        for (int part = 0; part < CH / 128; part++) {
+            const int cnt = (part + 1) * 128;
             qaddr = q0;
+            if constexpr (LOOP == 0)
+                asm volatile(FA_PGROUP4_ASM
+                             : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
+                             : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_DN3(r3), [cnt] "s"(cnt)
+                             : FA_PGROUP4_CLOBBERS);
+            if constexpr (LOOP == 2)
+                asm volatile(FA_GROUP2_ASM
+                             : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
+                             : FA_DN0(r0), FA_DN1(r1), FA_LANE(lane), [cnt] "s"(cnt)
+                             : FA_GROUP2_CLOBBERS);
+            if constexpr (LOOP == 3)
+                asm volatile(FA_GROUP3_ASM
+                             : [i] "+s"(i), [addr] "+v"(addr), [qaddr] "+v"(qaddr)
+                             : FA_DN0(r0), FA_DN1(r1), FA_DN2(r2), FA_LANE(lane), [cnt] "s"(cnt)
+                             : FA_GROUP3_CLOBBERS);
+            hits += (int)(qaddr - q0);
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = (float)hits;
@@ -89,9 +90,9 @@ int main()
     const int blocks[] = {512, 768, 1024, 2048, 3072, 4096};
     for (int b : blocks) {
         for (int reps : {80}) {
-            run<0>("primary4", FA_PRIMARY4_VALU, b, reps, dsph, dout);
-            run<2>("trace2", FA_TRACE2_VALU, b, reps, dsph, dout);
-            run<3>("trace3", FA_TRACE3_VALU, b, reps, dsph, dout);
+            run<0>("pgroup4", FA_PGROUP4_VALU, b, reps, dsph, dout);
+            run<2>("group2", FA_GROUP2_VALU, b, reps, dsph, dout);
+            run<3>("group3", FA_GROUP3_VALU, b, reps, dsph, dout);
         }
     }
     return 0;
