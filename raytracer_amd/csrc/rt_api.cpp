@@ -415,7 +415,10 @@ DevCamera make_camera(const rt_camera *cam, int w, int h, int row_begin, int row
 int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
 {
     const int levels = max_depth + 1;
-    const size_t slots = (size_t)P * (size_t)levels;
+    // Level stride: the pixels rounded up so that no cache line of any per-slot array (16-byte
+    // records, 4-byte mask words) holds slots of two levels (see k_trace_levels).
+    const size_t stride = ((size_t)P + RT_LEVEL_ALIGN - 1) / RT_LEVEL_ALIGN * RT_LEVEL_ALIGN;
+    const size_t slots = stride * (size_t)levels;
     if (slots > (size_t)INT32_MAX)
         return fail(ctx, RT_ERR_LIMIT, "%d pixels x %d levels exceeds 2^31-1 hit-record slots", P, levels);
     const int words = std::max(1, (nl + 31) / 32);
@@ -447,7 +450,7 @@ int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
     if (!d.frame.counters)
         HIP_TRY(ctx, hipMalloc((void **)&d.frame.counters, RT_COUNTER_SLOTS * sizeof(DevCounters)));
     if (!d.frame.sched) HIP_TRY(ctx, hipMalloc((void **)&d.frame.sched, sizeof(DevSched)));
-    d.frame.P = P;
+    d.frame.P = (int)stride;
     d.frame.slots = (int)slots;
     d.frame.max_depth = max_depth;
     d.frame.mask_words = words;
@@ -479,6 +482,16 @@ int check_schedule(rt_ctx *ctx, DeviceState &d)
     if (!d.frame.sched) return RT_OK;
     DevSched sc;
     HIP_TRY(ctx, hipMemcpy(&sc, d.frame.sched, sizeof sc, hipMemcpyDeviceToHost));
+    static const bool trace = getenv("RT_HIP_SCHED_TRACE") != nullptr;
+    if (trace) {
+        std::vector<int> cnt(2 * (size_t)(d.last_depth + 2));
+        (void)hipMemcpy(cnt.data(), d.frame.cnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[rt_hip] trace launch: %.1f us;", (double)(sc.t_last - sc.t_first) * 0.01);
+        for (int k = 1; k <= sc.open_level && k < RT_DEV_MAX_LEVELS; k++)
+            fprintf(stderr, " L%d opens at %.1f (A %d B %d)", k, (double)(sc.t_open[k] - sc.t_first) * 0.01,
+                    cnt[2 * k], cnt[2 * k + 1]);
+        fprintf(stderr, "; level 0: A %d B %d\n", cnt[0], cnt[1]);
+    }
     if (sc.error)
         return fail(ctx, RT_ERR_HIP, "device %d: the level schedule stalled at level %d; the frame is incomplete",
                     d.device, sc.open_level);

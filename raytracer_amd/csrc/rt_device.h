@@ -109,10 +109,16 @@ struct DevSched {
     int done_a[RT_DEV_MAX_LEVELS];   // finished reflecting tiles of level k
     int open_level;                  // levels <= open_level have their final record counts
     int error;                       // set when a workgroup gave up waiting for a level
+    // Timeline of the launch in ticks of the constant 100 MHz clock (wall_clock64): first claim,
+    // the opening of every level, last exit.  Written only by builds with -DRT_SCHED_TIMELINE and
+    // printed by the host when RT_HIP_SCHED_TRACE is set.
+    unsigned long long t_first, t_last;
+    unsigned long long t_open[RT_DEV_MAX_LEVELS];
 };
 
 // Hit records: the bounce stack of every pixel, kept in HBM.  Level k of the frame
-// owns slots [k*P, (k+1)*P) (P = pixels of the render call).  Records whose surface
+// owns slots [k*P, (k+1)*P) (P = pixels of the render call, rounded up to RT_LEVEL_ALIGN so
+// that levels never share a cache line in any per-slot array).  Records whose surface
 // needs a reflection trace ("A": specular != 0 and k < max_depth) are appended from
 // the front of the level, the others ("B") from the back, so each level is two dense
 // queues and no index arrays are needed.
@@ -121,6 +127,7 @@ struct DevSched {
 //                                         the pixel index at level 0 (int bits)
 //   refl[slot] = {rgb of the reflected Shade(), valid}   written by the child
 //   mask[w*slots + slot] = bit l%32 of word l/32 set when light l is occluded
+#define RT_LEVEL_ALIGN 64
 struct DevFrame {
     float4 *recA;
     float4 *recB;
@@ -129,7 +136,7 @@ struct DevFrame {
     int *cnt;              // cnt[2*k] = A records of level k, cnt[2*k+1] = B records
     DevCounters *counters;
     DevSched *sched;
-    int P;                 // pixels of this render call
+    int P;                 // level stride: pixels of this render call rounded up to RT_LEVEL_ALIGN
     int slots;             // P * (max_depth + 1)
     int max_depth;
     int mask_words;        // ceil(nl / 32), at least 1

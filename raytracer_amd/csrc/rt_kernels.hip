@@ -389,6 +389,7 @@ __global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam,
 // lane's rays could hit: (first index << 8) | reject mask; they return early when some
 // thread's queue is full.
 #define QUEUE_SLOTS 16
+#define EXACT_BATCH 2   // candidates per lane whose sphere data is in flight together
 #define QUEUE_INTS (QUEUE_SLOTS * 256)
 static_assert(GRP_CHUNK / FA_TRIP <= QUEUE_SLOTS, "one queue slot per trip of balls");
 static_assert(RT_GROUP == FA_TRIP && RT_SPH_PAD == FA_TRIP * RT_GROUP, "a trip of a SEL loop is one group");
@@ -445,10 +446,15 @@ __device__ __forceinline__ unsigned wave_or(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane(x, 63);
 }
 
-// The generated loops for K rays; TRACE: the rays share a per-lane origin operand (`lane`),
-// otherwise the staged entries already hold -c'' (primary rays, K = 4).
-template <int K, bool TRACE>
-__device__ __forceinline__ void fa_group(int &i, unsigned &addr, unsigned &qaddr, const f4raw (&rq)[5],
+// The generated loops take the K rays of a lane at once.  Primary rays (TRACE false, K = 4): the
+// staged entries already hold -c'' and the four verdicts are combined into one reject mask.
+// Trace rays share a per-lane origin operand (`lane`) and come in two families:
+//   combined (SPLIT false, K <= 3)  one reject mask for the K rays of a record;
+//   split    (SPLIT true,  K <= 4)  the GROUP loop keeps one reject mask per ray (bits 8k..8k+7 of
+//                                   the stored word are ray k's) and the SEL loops run one ray
+//                                   at a time (rq[0]) over the groups that ray's mask selects.
+template <int K, bool TRACE, bool SPLIT>
+__device__ __forceinline__ void fa_group(int &i, unsigned &addr, unsigned &qaddr, const f4raw (&rq)[4],
                                          const f4raw lane, const int cnt)
 {
 #define FA_RUN(NAME, ...)                                                  \
@@ -459,22 +465,26 @@ __device__ __forceinline__ void fa_group(int &i, unsigned &addr, unsigned &qaddr
     if constexpr (!TRACE) {
         static_assert(K == 4, "the primary loops take four rays");
         FA_RUN(FA_PGROUP4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]));
-    } else {
-        static_assert(K >= 1 && K <= 5, "one loop per ray count 1..5");
-        if constexpr (K == 1) FA_RUN(FA_GROUP1, FA_DN0(rq[0]), FA_LANE(lane));
+    } else if constexpr (K == 1) {
+        FA_RUN(FA_GROUP1, FA_DN0(rq[0]), FA_LANE(lane));
+    } else if constexpr (!SPLIT) {
+        static_assert(K <= 3, "combined loops exist for up to three rays");
         if constexpr (K == 2) FA_RUN(FA_GROUP2, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_LANE(lane));
         if constexpr (K == 3) FA_RUN(FA_GROUP3, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_LANE(lane));
+    } else {
+        static_assert(K <= 4, "split loops exist for up to four rays");
+        if constexpr (K == 2) FA_RUN(FA_GROUPS2, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_LANE(lane));
+        if constexpr (K == 3) FA_RUN(FA_GROUPS3, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_LANE(lane));
         if constexpr (K == 4)
-            FA_RUN(FA_GROUP4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_LANE(lane));
-        if constexpr (K == 5)
-            FA_RUN(FA_GROUP5, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_DN4(rq[4]), FA_LANE(lane));
+            FA_RUN(FA_GROUPS4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_LANE(lane));
     }
 #undef FA_RUN
 }
 
+// SEL loop for the K rays rq[0..K-1] (primary: K = 4; split trace walks call it with K = 1).
 template <int K, bool TRACE>
 __device__ __forceinline__ void fa_sel(unsigned long long &wlo, unsigned long long &whi, int &trip0, unsigned &qaddr,
-                                       const f4raw (&rq)[5], const f4raw lane, const unsigned addr0,
+                                       const f4raw (&rq)[4], const f4raw lane, const unsigned addr0,
                                        const unsigned qlim)
 {
 #define FA_RUN(NAME, ...)                                                                    \
@@ -485,93 +495,173 @@ __device__ __forceinline__ void fa_sel(unsigned long long &wlo, unsigned long lo
     if constexpr (!TRACE) {
         FA_RUN(FA_PSEL4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]));
     } else {
+        static_assert(K >= 1 && K <= 3, "one combined SEL loop per ray count 1..3");
         if constexpr (K == 1) FA_RUN(FA_SEL1, FA_DN0(rq[0]), FA_LANE(lane));
         if constexpr (K == 2) FA_RUN(FA_SEL2, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_LANE(lane));
         if constexpr (K == 3) FA_RUN(FA_SEL3, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_LANE(lane));
-        if constexpr (K == 4)
-            FA_RUN(FA_SEL4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_LANE(lane));
-        if constexpr (K == 5)
-            FA_RUN(FA_SEL5, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_DN4(rq[4]), FA_LANE(lane));
     }
 #undef FA_RUN
 }
 
-// One staged chunk of `cnt` spheres (a multiple of RT_SPH_PAD) for K rays per lane.
-// exact(sphere, host index) is called, per lane, for every sphere of the chunk the lane's
-// rays could hit, with the sphere's {centre, r*r} and host primitive index read from
-// sph / orig (the chunk's part of DevScene::sph / sph_orig; the next candidate's data is
-// fetched while the current one is evaluated).  The order of the calls is not the spheres'
-// host order.  candidates counts the calls, trips the trips of FA_TRIP balls or spheres the
-// filter loops ran.  Every lane of the wave must be active.
+// RT_PHASE_CLOCKS (profiling builds only): the wave's clock ticks per phase of a tile replace
+// the work counters in DevCounters, word p = phase p: 0 claim, 1 record setup, 2 GROUP loops,
+// 3 bitmap, 4 SEL loops, 5 exact pass, 6 planes and triangles, 7 results and record push.
+#ifdef RT_PHASE_CLOCKS
+struct PhaseClock {
+    unsigned long long t_last, clk[8];
+};
+#define PHASE_MARK(tcref, p)                                            \
+    {                                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();   \
+        (tcref).clk[p] += now_ - (tcref).t_last;                        \
+        (tcref).t_last = now_;                                          \
+    }
+#else
+struct PhaseClock {};
+#define PHASE_MARK(tcref, p)
+#endif
+
+// What the filter loops of a walk ran, in entries (spheres or balls) per lane.
+struct FilterWork {
+    int candidates;   // calls of the exact evaluation (this lane's)
+    int terms;        // per-origin terms formed (wave-uniform)
+    int ray_tests;    // (ray, entry) pairs evaluated (wave-uniform)
+};
+
+template <int N>
+struct RayIndex {
+    static constexpr int value = N;
+};
+
+// The sphere trips a wave-uniform bitmap names (bit b of wlo = trip b ^ 7, whi 64 trips later),
+// for the rays rq[0..K-1], then the exact evaluation of every
+// lane's queued candidates: exact(sphere {centre, r*r}, host index), EXACT_BATCH candidates per
+// lane at a time with their data fetched together.  Returns the trips run.
 template <int K, bool TRACE, class Exact>
-__device__ __forceinline__ void walk_chunk(const float4 *lds, const float4 *ldg, int *cand, const int cnt,
-                                           const float4 *sph, const int *orig, const f4raw (&rq)[5],
-                                           const f4raw lane_g, const f4raw lane, int &candidates, int &trips,
-                                           Exact &&exact)
+__device__ __forceinline__ int run_selected(const float4 *lds, int *cand, const float4 *sph, const int *orig,
+                                            const f4raw (&rq)[4], const f4raw lane, unsigned long long wlo,
+                                            unsigned long long whi, int &candidates, PhaseClock &pc, Exact &&exact)
 {
     const unsigned q0 = lds_offset(cand) + 4u * threadIdx.x;
     const unsigned qlim = lds_offset(cand) + QUEUE_SLOTS * FA_QUEUE_STRIDE;
-    const int ngroups = cnt / RT_GROUP, ntrips = ngroups / FA_TRIP;
-#if !defined(RT_EXPERIMENT) || RT_EXPERIMENT < 3   // RT_EXPERIMENT: timing builds only, wrong images
-    {
-        int i = 0;
-        unsigned addr = lds_offset(ldg), qaddr = q0;
-        fa_group<K, TRACE>(i, addr, qaddr, rq, lane_g, ngroups);
-        trips += ntrips;
-    }
-#endif
-    // Pass bits of 32 groups per word (bit 8t + b = group 8(4*word + t) + 7 - b), wave-wide.
-    static_assert(GRP_WORDS == 4, "the bitmap of a chunk is two 64-bit halves");
-    unsigned words[GRP_WORDS];
-#pragma unroll
-    for (int wd = 0; wd < GRP_WORDS; wd++) {
-        unsigned bits = 0u;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int trip = 4 * wd + t;
-            if (trip < ntrips) bits |= (((unsigned)cand[trip * 256 + threadIdx.x] & 0xffu) ^ 0xffu) << (8 * t);
-        }
-        words[wd] = wave_or(bits);
-    }
-    unsigned long long wlo = (unsigned long long)words[0] | ((unsigned long long)words[1] << 32);
-    unsigned long long whi = (unsigned long long)words[2] | ((unsigned long long)words[3] << 32);
-    int trip0 = 0;
-#if defined(RT_EXPERIMENT) && RT_EXPERIMENT >= 2
-    wlo = whi = 0ull;
-#endif
+    int trip0 = 0, trips = 0;
 #pragma clang loop unroll(disable)
     while ((wlo | whi) != 0ull) {
         unsigned qaddr = q0;
         trips += __popcll(wlo) + __popcll(whi);
         fa_sel<K, TRACE>(wlo, whi, trip0, qaddr, rq, lane, lds_offset(lds), qlim);
         trips -= __popcll(wlo) + __popcll(whi);   // what a full queue left for the next call
+        PHASE_MARK(pc, 4)
         CandidateWalk walk(cand, (int)((qaddr - q0) / FA_QUEUE_STRIDE));
-        int li = walk.next();
-        float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
-        int og = 0;
-        if (li >= 0) {
-            sp = sph[li];
-            og = orig[li];
-        }
+        int li[EXACT_BATCH];
+#pragma unroll
+        for (int k = 0; k < EXACT_BATCH; k++) li[k] = k == 0 || li[k - 1] >= 0 ? walk.next() : -1;
 #pragma clang loop unroll(disable)
-        while (__ballot(li >= 0) != 0ull) {
-            const int ln = li >= 0 ? walk.next() : -1;
-            float4 spn = sp;
-            int ogn = og;
-            if (ln >= 0) {
-                spn = sph[ln];
-                ogn = orig[ln];
+        while (__ballot(li[0] >= 0) != 0ull) {
+            float4 sp[EXACT_BATCH];
+            int og[EXACT_BATCH];
+#pragma unroll
+            for (int k = 0; k < EXACT_BATCH; k++) {
+                const int i = li[k] >= 0 ? li[k] : 0;
+                sp[k] = sph[i];
+                og[k] = orig[i];
             }
-            if (li >= 0) {
-                candidates++;
-#if !defined(RT_EXPERIMENT) || RT_EXPERIMENT < 1
-                exact(sp, og);
-#endif
+#pragma unroll
+            for (int k = 0; k < EXACT_BATCH; k++) {
+                if (li[k] >= 0) {
+                    candidates++;
+                    exact(sp[k], og[k]);
+                }
             }
-            li = ln;
-            sp = spn;
-            og = ogn;
+#pragma unroll
+            for (int k = 0; k < EXACT_BATCH; k++)
+                li[k] = (k == 0 ? li[EXACT_BATCH - 1] : li[k - 1]) >= 0 ? walk.next() : -1;
         }
+        PHASE_MARK(pc, 5)
+    }
+    return trips;
+}
+
+// One staged chunk of `cnt` spheres (a multiple of RT_SPH_PAD) for K rays per lane: a GROUP
+// loop over the chunk's bounding balls, the lanes' pass bits ORed over the wave, SEL loops over
+// the groups some lane may hit, the exact evaluation of what they queue.
+//   SPLIT false: one bitmap for the K rays of a lane; exact(RayIndex<-1>, sphere, host index)
+//     evaluates all of them.  Right when the rays are close to each other: the four pixels of
+//     a primary lane, the two or three rays of a record in a scene with two lights.
+//   SPLIT true (trace rays): with more lights the rays of a record point in unrelated
+//     directions, so every ray k has its own bitmap and runs only the groups IT may hit, one
+//     ray per SEL loop; exact(RayIndex<k>, sphere, host index) evaluates ray k.
+// The sphere's {centre, r*r} and host primitive index come from sph / orig (the chunk's part of
+// DevScene::sph / sph_orig).  The order of the calls is not the spheres' host order.  Every lane
+// of the wave must be active.
+template <int K, bool TRACE, bool SPLIT, class Exact>
+__device__ __forceinline__ void walk_chunk(const float4 *lds, const float4 *ldg, int *cand, const int cnt,
+                                           const float4 *sph, const int *orig, const f4raw (&rq)[4],
+                                           const f4raw lane_g, const f4raw lane, FilterWork &fw, PhaseClock &pc,
+                                           Exact &&exact)
+{
+    static_assert(TRACE || !SPLIT, "primary rays use the combined loops");
+    constexpr bool split = SPLIT && K > 1;
+    const int ngroups = cnt / RT_GROUP, ntrips = ngroups / FA_TRIP;
+    PHASE_MARK(pc, 1)
+    {
+        int i = 0;
+        unsigned addr = lds_offset(ldg), qaddr = lds_offset(cand) + 4u * threadIdx.x;
+        fa_group<K, TRACE, split>(i, addr, qaddr, rq, lane_g, ngroups);
+        fw.terms += TRACE ? ntrips * FA_TRIP : 0;
+        fw.ray_tests += ntrips * FA_TRIP * K;
+    }
+    PHASE_MARK(pc, 2)
+    // Pass bits of 32 groups per word (bit 8t + b = group 8(4*word + t) + 7 - b), wave-wide,
+    // one bitmap per ray (split) or one for all.
+    static_assert(GRP_WORDS == 4, "the bitmap of a chunk is two 64-bit halves");
+    constexpr int NB = split ? K : 1;
+    unsigned words[NB][GRP_WORDS];
+#pragma unroll
+    for (int wd = 0; wd < GRP_WORDS; wd++) {
+        unsigned bits[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) bits[k] = 0u;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int trip = 4 * wd + t;
+            if (trip < ntrips) {
+                const unsigned w = ~(unsigned)cand[trip * 256 + threadIdx.x];
+#pragma unroll
+                for (int k = 0; k < NB; k++) bits[k] |= ((w >> (8 * k)) & 0xffu) << (8 * t);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++) words[k][wd] = wave_or(bits[k]);
+    }
+    PHASE_MARK(pc, 3)
+    if constexpr (!split) {
+        const int trips = run_selected<K, TRACE>(lds, cand, sph, orig, rq, lane,
+                                                 (unsigned long long)words[0][0] | ((unsigned long long)words[0][1] << 32),
+                                                 (unsigned long long)words[0][2] | ((unsigned long long)words[0][3] << 32),
+                                                 fw.candidates, pc,
+                                                 [&](const float4 sp, const int og) { exact(RayIndex<-1>(), sp, og); });
+        fw.terms += TRACE ? trips * FA_TRIP : 0;
+        fw.ray_tests += trips * FA_TRIP * K;
+    } else {
+        int trips = 0;
+        auto one_ray = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k < K) {
+                const f4raw one[4] = {rq[k], rq[k], rq[k], rq[k]};
+                trips += run_selected<1, true>(lds, cand, sph, orig, one, lane,
+                                               (unsigned long long)words[k][0] | ((unsigned long long)words[k][1] << 32),
+                                               (unsigned long long)words[k][2] | ((unsigned long long)words[k][3] << 32),
+                                               fw.candidates, pc,
+                                               [&](const float4 sp, const int og) { exact(kc, sp, og); });
+            }
+        };
+        one_ray(RayIndex<0>());
+        one_ray(RayIndex<1>());
+        one_ray(RayIndex<2>());
+        one_ray(RayIndex<3>());
+        fw.terms += trips * FA_TRIP;
+        fw.ray_tests += trips * FA_TRIP;
     }
 }
 
@@ -616,7 +706,8 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
         stage_chunk(lds, ldg, s.sph_cam, s.grp_cam, 0, nsp);
         __syncthreads();
     }
-    int candidates = 0, trips = 0;
+    FilterWork fw = {0, 0, 0};
+    PhaseClock pc = {};
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = tile / tiles_x;
         const int x0 = tx * 32 + (wave & 1) * 16 + (lane & 7) * 2;
@@ -638,10 +729,9 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
             best_t[k] = RT_FLT_MAX;
             best_prim[k] = INT_MAX;
         }
-        f4raw rq[5];
+        f4raw rq[4];
 #pragma unroll
         for (int k = 0; k < PRIM_PX; k++) rq[k] = filter_ray(fo, d[k]);
-        rq[4] = rq[0];
         for (int base = 0; base < nsp; base += SPH_CHUNK) {
             const int cnt = min(SPH_CHUNK, nsp - base);
             if (!single) {
@@ -652,8 +742,8 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
             // Exact evaluation of a candidate: objects.cs:112-121 literally; among equal
             // distances the lower host index wins, as the strict `<` of MyApplication.cs:361
             // decides when the primitives are scanned in host order.
-            walk_chunk<PRIM_PX, false>(lds, ldg, cand, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_g, fo.lane,
-                                       candidates, trips, [&](const float4 sp, const int orig) {
+            walk_chunk<PRIM_PX, false, false>(lds, ldg, cand, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_g, fo.lane,
+                                       fw, pc, [&](auto, const float4 sp, const int orig) {
                 const f3 op = sub3(o, xyz(sp));
                 const float c = dot3(op, op) - sp.w;
 #pragma unroll
@@ -699,12 +789,13 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
         }
         push_records<PRIM_PX>(f, s, 0, blk, rec_valid, rec_prim, rec_hit, d, rec_parent);
     }
-    // Counter words in the order of DevCounters; trips is wave-uniform: every lane ran them,
-    // on PRIM_PX rays each.
-    const unsigned long long cand_total = (unsigned long long)wave_sum(candidates);
-    const unsigned long long tests = (unsigned long long)trips * (64ull * FA_TRIP * PRIM_PX);
+    // Counter words in the order of DevCounters; the filter's counts are the same in every lane.
+    const unsigned long long cand_total = (unsigned long long)wave_sum(fw.candidates);
+    const unsigned long long tests = 64ull * (unsigned long long)fw.ray_tests;
     const unsigned long long v[COUNTER_WORDS] = {0ull, 0ull, 0ull, cand_total, tests, 0ull, tests, cand_total};
+#ifndef RT_PHASE_CLOCKS
     flush_counters(f, cnt_sh, v);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -733,24 +824,24 @@ struct Rays {
     Closest sec;
 };
 
-template <int LC, bool SEC>
+template <int LC, bool SEC, bool SPLIT>
 __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, float4 *ldg, int *cand, const bool single,
-                                         const f3 o, Rays<LC, SEC> &r, TestCount &tc)
+                                         const f3 o, Rays<LC, SEC> &r, TestCount &tc, PhaseClock &pc)
 {
     constexpr int NR = LC + (SEC ? 1 : 0);
-    static_assert(NR >= 1 && NR <= 5, "one filter loop per ray count 1..5");
+    static_assert(NR >= 1 && NR <= 4, "one GROUP loop per ray count 1..4");
     // Ray operands of the filter loop: light rays first, the reflection ray last.
     const FilterOrigin fo = filter_origin(s, o);
-    f4raw rq[5];
+    f4raw rq[4];
 #pragma unroll
-    for (int l = 0; l < 5; l++) rq[l] = f4raw{0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < 4; l++) rq[l] = f4raw{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int l = 0; l < LC; l++) rq[l] = filter_ray(fo, r.sh_d[l]);
     if (SEC) rq[LC] = filter_ray(fo, r.sec_d);
 
     float best_t = RT_FLT_MAX;
     int best_prim = INT_MAX;   // host index of the closest sphere so far
-    int trips = 0;
+    FilterWork fw = {0, 0, 0};
     const int nsp = s.ns_padded;
     for (int base = 0; base < nsp; base += SPH_CHUNK) {
         const int cnt = min(SPH_CHUNK, nsp - base);
@@ -759,16 +850,18 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, float4 
             stage_chunk(lds, ldg, s.sph_f, s.grp_f, base, cnt);
             __syncthreads();
         }
-        // Exact evaluation of a candidate (Sphere.Intersect objects.cs:112-121, literally).
+        // Exact evaluation of a candidate (Sphere.Intersect objects.cs:112-121, literally) for ray
+        // k of the record (lights first, then the reflection ray), or for all rays (k = -1).
         // Closest hit: among equal distances the lower host index wins (MyApplication.cs:361);
         // shadow rays: the lowest host index among the occluders is the one the reference
         // meets first (MyApplication.cs:373-378).
-        walk_chunk<NR, true>(lds, ldg, cand, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_g, fo.lane, tc.exact,
-                             trips, [&](const float4 sp, const int orig) {
+        walk_chunk<NR, true, SPLIT>(lds, ldg, cand, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_g, fo.lane, fw,
+                                    pc, [&](auto kc, const float4 sp, const int orig) {
+            constexpr int k = decltype(kc)::value;
             const f3 op = sub3(o, xyz(sp));
             const float c = dot3(op, op) - sp.w;
             float t;
-            if (SEC) {
+            if constexpr (SEC && (k < 0 || k == LC)) {
                 const float x = dot3(r.sec_d, op);
                 if (sphere_maybe(x, r.sec_a * c) && sphere_root(x, c, r.sec_a, t) && t > RT_EPS &&
                     (t < best_t || (t == best_t && orig < best_prim))) {
@@ -778,6 +871,7 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, float4 
             }
 #pragma unroll
             for (int l = 0; l < LC; l++) {
+                if (k >= 0 && l != k) continue;
                 const float x = dot3(r.sh_d[l], op);
                 if (sphere_maybe(x, r.sh_a[l] * c) && sphere_root(x, c, r.sh_a[l], t) && t > RT_EPS &&
                     t < r.sh_dist[l])
@@ -785,13 +879,15 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, float4 
             }
         });
     }
-    tc.filt_terms += trips * FA_TRIP;
-    tc.filt_rays += trips * FA_TRIP * NR;
+    tc.exact += fw.candidates;
+    tc.filt_terms += fw.terms;
+    tc.filt_rays += fw.ray_tests;
     if (SEC) {
         r.sec.t = best_t;
         r.sec.prim = best_prim;
     }
     // ---- planes --------------------------------------------------------------------
+    PHASE_MARK(pc, 5)
     for (int j = 0; j < s.np; j++) {
         const float4 pl = cload(s.pl, j);
         const f3 n = xyz(pl);
@@ -835,10 +931,10 @@ __device__ __forceinline__ f3 record_normal(const DevScene &s, int prim, int typ
 
 
 // One chunk of LC lights (plus the reflection ray when SEC) for one record.
-template <int LC, bool SEC>
+template <int LC, bool SEC, bool SPLIT>
 __device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, float4 *ldg, int *cand, const bool single, const f3 hit,
                                             const f3 view, const f3 normal, int l0, uint32_t &mask_word,
-                                            Closest &sec_out, f3 &sec_dir, TestCount &tc)
+                                            Closest &sec_out, f3 &sec_dir, TestCount &tc, PhaseClock &pc)
 {
     Rays<LC, SEC> r;
 #pragma unroll
@@ -857,7 +953,8 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, floa
         r.sec.t = RT_FLT_MAX;
         r.sec.prim = INT_MAX;
     }
-    traverse<LC, SEC>(s, lds, ldg, cand, single, hit, r, tc);
+    traverse<LC, SEC, SPLIT>(s, lds, ldg, cand, single, hit, r, tc, pc);
+    PHASE_MARK(pc, 6)
 #pragma unroll
     for (int l = 0; l < LC; l++) {
         const bool occluded = r.sh_first[l] != INT_MAX;
@@ -886,8 +983,9 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, floa
 template <bool SEC, int LCMAX>
 __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f, float4 *lds, float4 *ldg, int *cand, int *blk,
                                            const bool single, const int level, const int tile, const int n,
-                                           TestCount &tc)
+                                           TestCount &tc, PhaseClock &pc)
 {
+    PHASE_MARK(pc, 0)
     const int i = tile * 256 + threadIdx.x;
     const bool active = i < n;
     const int ii = active ? i : n - 1;
@@ -905,24 +1003,39 @@ __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f,
     int l0 = 0;
     bool first = true;
     const int nl = s.nl;
-    // Lights in chunks of 4 / 2 / 1; the reflection ray rides with the first chunk.
+    // Lights in chunks of up to 2 (LCMAX 2: scenes with fewer than four lights, combined filter
+    // loops, at most three rays per walk) or up to 4 (LCMAX 4: split loops, at most four rays per
+    // walk, so the chunk that carries the reflection ray has one light fewer).
+#define RT_CHUNK(LC_, SEC_) trace_chunk<LC_, SEC_, (LCMAX >= 4)>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc, pc)
     while (l0 < nl || (SEC && first)) {
-        const int rem = nl - l0;
-        if (LCMAX >= 4 && rem >= 4) {
-            if (SEC && first) trace_chunk<LCMAX >= 4 ? 4 : 2, true>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-            else trace_chunk<LCMAX >= 4 ? 4 : 2, false>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-            l0 += 4;
+        const int rem = min(nl - l0, 32 - (l0 & 31));   // a walk's lights share one mask word
+        const bool with_sec = SEC && first;
+        bool done = false;
+        if constexpr (LCMAX >= 4) {
+            if (!with_sec && rem >= 4) {
+                RT_CHUNK(4, false);
+                l0 += 4;
+                done = true;
+            } else if (rem >= 3) {
+                if (with_sec) RT_CHUNK(3, true);
+                else RT_CHUNK(3, false);
+                l0 += 3;
+                done = true;
+            }
+        }
+        if (done) {
         } else if (rem >= 2) {
-            if (SEC && first) trace_chunk<2, true>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-            else trace_chunk<2, false>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            if (with_sec) RT_CHUNK(2, true);
+            else RT_CHUNK(2, false);
             l0 += 2;
         } else if (rem == 1) {
-            if (SEC && first) trace_chunk<1, true>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
-            else trace_chunk<1, false>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            if (with_sec) RT_CHUNK(1, true);
+            else RT_CHUNK(1, false);
             l0 += 1;
         } else {
-            trace_chunk<0, true>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc);
+            RT_CHUNK(0, true);
         }
+#undef RT_CHUNK
         first = false;
         if (l0 > 0 && ((l0 & 31) == 0 || l0 >= nl)) {
             if (active) f.mask[(size_t)((l0 - 1) >> 5) * (size_t)f.slots + slot] = word;
@@ -946,6 +1059,7 @@ __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f,
         const f3 rh[1] = {hit2}, rd[1] = {sec_dir};
         push_records<1>(f, s, level + 1, blk, rv, rp, rh, rd, rparent);
     }
+    PHASE_MARK(pc, 7)
 }
 
 __device__ __forceinline__ void flush_test_counts(const DevFrame &f, unsigned long long *cnt_sh, const TestCount &tc)
@@ -977,9 +1091,10 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
         __syncthreads();
     }
     TestCount tc = {0, 0, 0, 0, 0, 0};
+    PhaseClock pc = {};
     // Workgroup-uniform trip count: the sphere chunks are staged between barriers.
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
-        trace_tile<SEC, LCMAX>(s, f, lds, ldg, cand, blk, single, level, tile, n, tc);
+        trace_tile<SEC, LCMAX>(s, f, lds, ldg, cand, blk, single, level, tile, n, tc, pc);
     flush_test_counts(f, cnt_sh, tc);
 }
 
@@ -1001,10 +1116,12 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
 //     an A tile waits for its stores (vmcnt 0 in every wave, then a barrier) and only then
 //     counts the tile as done; the workgroup that counts the level's last tile publishes
 //     open_level = k+1.  No write-back fence is needed.
-//   * a taker (thread 0) reads open_level with a device-scope load on every claim; when it
-//     sees a level it has not seen before it invalidates the caches ONCE (acquire fence), reads
-//     that level's record counts, and only then hands tiles of that level to the workgroup.
-//     Nobody reads a level's slots before the level is open, so no stale line can survive.
+//   * a taker (thread 0) reads open_level with a device-scope load on every claim and reads a
+//     newly opened level's record counts before it hands tiles of that level to the workgroup.
+//     No cache invalidation is needed either: nobody reads a slot of a level before the level is
+//     open, and the levels' slot ranges start at multiples of RT_LEVEL_ALIGN slots, so no cache
+//     line of recA / recB / mask holds slots of two levels: a line that a workgroup reads from
+//     an open level cannot have been cached, by any XCD, before its last write of this launch.
 // The chain ends at the first open level without A records (level max_depth never has any);
 // a workgroup leaves when the chain has ended and no B tile is left to claim.  A workgroup
 // that waits longer than SCHED_SPIN_LIMIT polls for a level to open sets sched->error and
@@ -1013,7 +1130,7 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
 #define SCHED_JOB_EXIT 0
 #define SCHED_JOB_A 1
 #define SCHED_JOB_B 2
-#define SCHED_SPIN_LIMIT (1u << 21)   // x ~14 us per poll: ~30 s
+#define SCHED_SPIN_LIMIT (1u << 23)   // x ~3.5 us per poll: ~30 s
 
 __device__ __forceinline__ int sched_load(const int *p)
 {
@@ -1022,7 +1139,7 @@ __device__ __forceinline__ int sched_load(const int *p)
 
 // Thread 0's view of the schedule.
 struct Taker {
-    int seen_open;        // levels <= seen_open: caches invalidated after they opened, counts read
+    int seen_open;        // levels <= seen_open: record counts read
     int b_level;          // lowest level whose B queue may still hold an unclaimed tile
     bool a_left;          // level seen_open may still hold an unclaimed A tile
     unsigned spins;
@@ -1044,7 +1161,14 @@ k_trace_levels(DevScene s, DevFrame f)
     const bool single = s.ns_padded <= SPH_CHUNK;
     bool staged = false;
     TestCount tc = {0, 0, 0, 0, 0, 0};
+    PhaseClock pc = {};
+#ifdef RT_PHASE_CLOCKS
+    pc.t_last = __builtin_readcyclecounter();
+#endif
     Taker tk = {-1, 0, false, 0u};
+#ifdef RT_SCHED_TIMELINE   // profiling builds only: two atomics per workgroup on one word cost ~20 us
+    if (threadIdx.x == 0) atomicCAS(&sc->t_first, 0ull, (unsigned long long)wall_clock64());
+#endif
     for (;;) {
         if (threadIdx.x == 0) {
             int kind = SCHED_JOB_EXIT, lvl = 0, tile = 0, n = 0;
@@ -1072,7 +1196,6 @@ k_trace_levels(DevScene s, DevFrame f)
                 }
                 const bool opened = open > tk.seen_open;
                 if (opened) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // once per level per workgroup
                     for (int k = tk.seen_open + 1; k <= open; k++) {
                         lv_a[k] = k < D ? sched_load(&f.cnt[2 * k]) : 0;
                         const int nb = sched_load(&f.cnt[2 * k + 1]);
@@ -1094,9 +1217,6 @@ k_trace_levels(DevScene s, DevFrame f)
                     break;
                 }
                 __builtin_amdgcn_s_sleep(127);
-                __builtin_amdgcn_s_sleep(127);
-                __builtin_amdgcn_s_sleep(127);
-                __builtin_amdgcn_s_sleep(127);
             }
             job[0] = kind;
             job[1] = lvl;
@@ -1112,22 +1232,36 @@ k_trace_levels(DevScene s, DevFrame f)
         }
         __syncthreads();   // job[] read by all, spheres staged
         if (kind == SCHED_JOB_A) {
-            trace_tile<true, LCMAX>(s, f, lds, ldg, cand, blk, single, lvl, tile, n, tc);
+            __builtin_amdgcn_s_setprio(3);   // the chain of levels is the launch's critical path
+            trace_tile<true, LCMAX>(s, f, lds, ldg, cand, blk, single, lvl, tile, n, tc, pc);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's record stores have reached memory
+            __builtin_amdgcn_s_setprio(0);
             __syncthreads();
             if (threadIdx.x == 0) {
 #ifdef RT_SCHED_RELEASE_FENCE
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #endif
                 const int tiles_a = (n + 255) >> 8;
-                if (atomicAdd(&sc->done_a[lvl], 1) + 1 == tiles_a)
+                if (atomicAdd(&sc->done_a[lvl], 1) + 1 == tiles_a) {
+#ifdef RT_SCHED_TIMELINE
+                    sc->t_open[lvl + 1] = (unsigned long long)wall_clock64();
+#endif
                     __hip_atomic_store(&sc->open_level, lvl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         } else {
-            trace_tile<false, LCMAX>(s, f, lds, ldg, cand, blk, single, lvl, tile, n, tc);
+            trace_tile<false, LCMAX>(s, f, lds, ldg, cand, blk, single, lvl, tile, n, tc, pc);
         }
     }
+#ifdef RT_SCHED_TIMELINE
+    if (threadIdx.x == 0) atomicMax(&sc->t_last, (unsigned long long)wall_clock64());
+#endif
+#ifdef RT_PHASE_CLOCKS
+    PHASE_MARK(pc, 0)
+    flush_counters(f, cnt_sh, pc.clk);
+#else
     flush_test_counts(f, cnt_sh, tc);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Frame times of the benchmark configurations on one GPU, and what a row partition over
+G GPUs would cost per rank (each rank's rows rendered alone on this GPU, one after the other).
+
+    python tools/config_sweep.py [--configs c2,c3,c5,split] [--frames 5]
+
+Prints one JSON object per measurement.  Device-resident timing (rt_render_rows_device on
+torch's current stream, wall clock around a synchronised batch of frames).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from raytracer_amd import Camera, RenderContext, default_scene, scene_1k, scene_64k  # noqa: E402
+
+
+def time_rows(ctx, cam, w, h, depth, rows, frames, profile=True):
+    """ms per call of rt_render_rows_device over `rows` = [(y0, y1), ...] rendered back to back."""
+    bufs = [torch.empty((y1 - y0, w), dtype=torch.int32, device="cuda") for y0, y1 in rows]
+    stream = torch.cuda.current_stream().cuda_stream
+    out = []
+    for (y0, y1), buf in zip(rows, bufs):
+        ctx.set_profiling(False)
+        ctx.render_rows_device(cam, w, h, y0, y1, depth, buf.data_ptr(), stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            ctx.render_rows_device(cam, w, h, y0, y1, depth, buf.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / frames * 1e3
+        st = None
+        if profile:
+            ctx.set_profiling(True)
+            ctx.render_rows_device(cam, w, h, y0, y1, depth, buf.data_ptr(), stream)
+            st = ctx.stats()
+        out.append((ms, st))
+    return out
+
+
+def rays_of(st):
+    return st["rays_primary"] + st["rays_shadow"] + st["rays_secondary"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="c2,c3,c5,split")
+    ap.add_argument("--frames", type=int, default=5)
+    ap.add_argument("--c5-size", default="1920x1080")
+    args = ap.parse_args()
+    want = set(args.configs.split(","))
+    cam = Camera()
+    ctx = RenderContext([0])
+
+    def single(name, flat, w, h, depth, frames):
+        ctx.set_scene(flat)
+        (ms, st), = time_rows(ctx, cam, w, h, depth, [(0, h)], frames)
+        print(json.dumps({"config": name, "size": f"{w}x{h}", "max_depth": depth, "ms_per_frame": round(ms, 4),
+                          "Mrays_per_s": round(rays_of(st) / ms / 1e3, 1), "rays": rays_of(st),
+                          "primary_ms": round(st["primary_ms"], 4), "trace_ms": round(st["trace_ms"], 4),
+                          "shade_ms": round(st["shade_ms"], 4),
+                          "filter_ray_tests": st["filter_ray_tests"], "sphere_tests": st["sphere_tests"],
+                          "exact_candidates": st["exact_candidates"]}), flush=True)
+
+    if "c2" in want:
+        single("C2 default scene, primary + shadow only", default_scene().flatten(), 1920, 1080, 0, args.frames * 4)
+    if "c3" in want:
+        single("C3 1k spheres, 4 bounces", scene_1k().flatten(), 3840, 2160, 4, args.frames * 4)
+    if "c4" in want:
+        single("C4 resolution on one GPU", scene_1k().flatten(), 7680, 4320, 4, args.frames)
+    if "c5" in want:
+        w, h = (int(v) for v in args.c5_size.split("x"))
+        single("C5 64k spheres, 16 lights, 8 bounces", scene_64k().flatten(), w, h, 8, max(1, args.frames // 3))
+    if "split" in want:
+        ctx.set_scene(scene_1k().flatten())
+        w, h, depth = 3840, 2160, 4
+        (full_ms, _), = time_rows(ctx, cam, w, h, depth, [(0, h)], args.frames * 4, profile=False)
+        for G in (2, 4, 8):
+            rows = [((h * r) // G, (h * (r + 1)) // G) for r in range(G)]
+            res = time_rows(ctx, cam, w, h, depth, rows, args.frames * 4)
+            ms = [round(m, 4) for m, _ in res]
+            print(json.dumps({"config": f"C3 frame as {G} contiguous row blocks", "full_frame_ms": round(full_ms, 4),
+                              "block_ms": ms, "max_ms": max(ms), "sum_ms": round(sum(ms), 4),
+                              "primary_ms": [round(st["primary_ms"], 3) for _, st in res],
+                              "trace_ms": [round(st["trace_ms"], 3) for _, st in res],
+                              "shade_ms": [round(st["shade_ms"], 3) for _, st in res],
+                              "rays": [rays_of(st) for _, st in res],
+                              "efficiency_if_no_gather": round(full_ms / (G * max(ms)), 4)}), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

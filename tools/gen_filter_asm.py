@@ -60,6 +60,9 @@ DN = lambda k: 4 * k
 LANE = 20
 VADDR = 24
 MASK = 25
+# Per-ray reject masks of the split GROUP loops (ray k's verdict register sits in bank 1, 0, 3, 1
+# for k = 0..3 and must not share a bank with the mask it is shifted into).
+RAYMASK = (86, 87, 88, 90)
 SET = (lambda u: 26 + 4 * u, lambda u: 42 + 4 * u)
 QUAD = lambda i: 58 + 4 * i
 SA = lambda u: QUAD(u)
@@ -102,8 +105,9 @@ def group_size(K):
     return {1: 4, 2: 2, 3: 2, 4: 1, 5: 1}[K]
 
 
-def phase(L, K, trace, cur, ph, ball=False):
-    """Shifts the reject bits of the NB entries in register set `cur` into MASK."""
+def phase(L, K, trace, cur, ph, ball=False, split=False):
+    """Shifts the reject bits of the NB entries in register set `cur` into MASK, or with
+    `split` every ray's own reject bit into RAYMASK[k]."""
     s = SET[cur]
     px, py, pz, w = (lambda u: s(u)), (lambda u: s(u) + 1), (lambda u: s(u) + 2), (lambda u: s(u) + 3)
     if trace:
@@ -152,6 +156,16 @@ def phase(L, K, trace, cur, ph, ball=False):
                 x = TA(tmp[u, k])
                 check3(x, w(u))
                 L.append(f"v_fma_f32 v{vreg(u, k)}, v{x}, |v{x}|, v{w(u)}")
+        if split:
+            for u in us:
+                for k in range(K):
+                    m, v = RAYMASK[k], vreg(u, k)
+                    if ph == 0 and u == 0:
+                        L.append(f"v_lshrrev_b32 v{m}, 31, v{v}")
+                    else:
+                        check3(m, v)
+                        L.append(f"v_alignbit_b32 v{m}, v{m}, v{v}, 31")
+            continue
         for u in us:
             acc = SA(u)
             if K == 2:
@@ -177,17 +191,24 @@ def loads(L, which, byte_offset, first=False):
         L.append(f"ds_read_b128 v[{r}:{r + 3}], %[addr] offset:{byte_offset + 16 * u}")
 
 
-def group_loop(K, trace):
-    """GROUP loop: every trip of the ball array from entry i to cnt; masks stored per trip."""
+def group_loop(K, trace, split=False):
+    """GROUP loop: every trip of the ball array from entry i to cnt; masks stored per trip.
+    With `split` (2 <= K <= 4) the stored word holds one reject mask per ray, ray k's in bits
+    8k .. 8k+7."""
     L = []
     loads(L, 0, 0, first=True)
     L.append(".LFA_LOOP%=:")
     L.append("s_waitcnt lgkmcnt(0)")
     loads(L, 1, 16 * NB)
-    phase(L, K, trace, 0, 0, ball=True)
+    phase(L, K, trace, 0, 0, ball=True, split=split)
     L.append("s_waitcnt lgkmcnt(0)")
     loads(L, 0, 32 * NB)
-    phase(L, K, trace, 1, 1, ball=True)
+    phase(L, K, trace, 1, 1, ball=True, split=split)
+    if split:
+        for k in range(1, K):
+            src = RAYMASK[0] if k == 1 else MASK
+            check3(RAYMASK[k], src)
+            L.append(f"v_lshl_or_b32 v{MASK}, v{RAYMASK[k]}, {8 * k}, v{src}")
     L.append(f"ds_write_b32 %[qaddr], v{MASK}")
     L.append(f"v_add_u32 %[qaddr], {QSTRIDE}, %[qaddr]")
     L.append(f"s_add_u32 %[i], %[i], {2 * NB}")
@@ -295,12 +316,12 @@ def written_registers(lines):
     return sorted(regs)
 
 
-def emit(name, K, trace, kind):
-    lines = group_loop(K, trace) if kind == "group" else sel_loop(K, trace)
+def emit(name, K, trace, kind, split=False):
+    lines = group_loop(K, trace, split) if kind == "group" else sel_loop(K, trace)
     probe = []
-    phase(probe, K, trace, 0, 0, ball=(kind == "group"))
-    phase(probe, K, trace, 1, 1, ball=(kind == "group"))
-    valu = sum(1 for l in probe if l.startswith("v_")) + (2 if kind == "group" else 3)
+    phase(probe, K, trace, 0, 0, ball=(kind == "group"), split=split)
+    phase(probe, K, trace, 1, 1, ball=(kind == "group"), split=split)
+    valu = sum(1 for l in probe if l.startswith("v_")) + (2 if kind == "group" else 3) + (K - 1 if split else 0)
     what = "ball" if kind == "group" else "sphere"
     out = [f"// {name}: {kind} loop, {'shared origin' if trace else 'precomputed -c'}, {K} ray(s) per lane, "
            f"~{valu} VALU instructions per trip of {2 * NB} {what}s when nothing is queued"]
@@ -325,7 +346,7 @@ def main():
            "// Sphere-filter loops for gfx950 with a VGPR-bank-conflict-free register plan.",
            "// Register plan and calling convention: see the generator's module docstring.", ""]
     out.append("// Pinned operand registers (constraint strings).")
-    for k in range(5):
+    for k in range(4):
         out.append(f'#define FA_DN{k} "{{v[{DN(k)}:{DN(k) + 3}]}}"   // ray {k}: (e, dx, dy, dz)')
     out.append(f'#define FA_LANE "{{v[{LANE}:{LANE + 3}]}}"   // (Bx, By, Bz, C0), trace loops')
     out.append(f"#define FA_QUEUE_STRIDE {QSTRIDE}   // bytes between consecutive queue slots of one thread")
@@ -337,10 +358,18 @@ def main():
     out.append("")
     out += emit("FA_PSEL4", 4, False, "sel")
     out.append("")
-    for K in range(1, 6):
+    # Trace loops, two families.  Combined (scenes with few lights, K <= 3): the K rays of a
+    # record share one reject mask per ball and per sphere.  Split (K <= 4): the balls are
+    # tested for all K rays at once (they share the per-origin term) with one reject mask per
+    # ray, and the sphere trips are then run ray by ray (FA_SEL1), each ray over the groups
+    # its own mask selects.
+    for K in range(1, 4):
         out += emit(f"FA_GROUP{K}", K, True, "group")
         out.append("")
         out += emit(f"FA_SEL{K}", K, True, "sel")
+        out.append("")
+    for K in range(2, 5):
+        out += emit(f"FA_GROUPS{K}", K, True, "group", split=True)
         out.append("")
     with open(path, "w") as f:
         f.write("\n".join(out))
