@@ -26,12 +26,12 @@ struct DeviceState {
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {};  // begin, after primary, after trace, after shade, after gather copy
     int num_cus = 256;
-    int resident_blocks = 0, resident_nl = -1;   // k_trace_levels workgroups resident at once
+    int resident_blocks = 0;   // k_trace_levels workgroups resident at once (0: ask again, the scene changed)
 
     // scene
     DevScene scene{};
     std::vector<void *> scene_allocs;
-    float4 *sph_cam = nullptr, *grp_cam = nullptr;
+    float4 *cam_terms = nullptr;   // sph_cam, grp_cam, sup_cam, chk_cam in one allocation
     void *tex_mem[RT_MAX_TEXTURES] = {};
 
     // per-frame scratch
@@ -90,9 +90,8 @@ void free_scene(DeviceState &d)
 {
     for (void *p : d.scene_allocs) (void)hipFree(p);
     d.scene_allocs.clear();
-    if (d.sph_cam) (void)hipFree(d.sph_cam);
-    if (d.grp_cam) (void)hipFree(d.grp_cam);
-    d.sph_cam = d.grp_cam = nullptr;
+    if (d.cam_terms) (void)hipFree(d.cam_terms);
+    d.cam_terms = nullptr;
     const uchar4 *tex[RT_DEV_MAX_TEXTURES];
     int tw[RT_DEV_MAX_TEXTURES], th[RT_DEV_MAX_TEXTURES];
     memcpy(tex, d.scene.tex, sizeof tex);
@@ -136,11 +135,11 @@ int upload(rt_ctx *ctx, DeviceState &d, const std::vector<T> &host, const T **de
 }
 
 struct PackedScene {
-    std::vector<float4> sph, sph_f, grp_f, pl, tri, geo, mat, light_pos, light_col;
+    std::vector<float4> sph, sph_f, grp_f, sup_f, chk_f, pl, tri, geo, mat, light_pos, light_col;
     std::vector<int> sph_orig, pl_orig, tri_orig, class_prefix;
     uint32_t textures_used = 0;
     float sph_center[3] = {0.f, 0.f, 0.f};
-    float sph_l1max = 0.f, sph_sc = 0.f, grp_rmax = 0.f;
+    float sph_l1max = 0.f, sph_sc = 0.f, grp_rmax = 0.f, sup_rmax = 0.f, chk_rmax = 0.f;
 };
 
 bool usable_sphere(const float4 &s)
@@ -212,8 +211,7 @@ void build_filter_arrays(PackedScene &out)
     }
     const float4 never = make_float4(0.f, 0.f, 0.f, -INFINITY);
     out.sph_f.assign(n, never);
-    out.grp_f.assign(n / RT_GROUP, never);
-    double l1max = 0.0, p2max = 0.0, r2max = 0.0, grmax = 0.0;
+    double l1max = 0.0, p2max = 0.0, r2max = 0.0;
     auto entry = [&](const double c[3], double r2, float4 *dst) {
         const float px = (float)(c[0] - cen[0]), py = (float)(c[1] - cen[1]), pz = (float)(c[2] - cen[2]);
         const double p2 = (double)px * px + (double)py * py + (double)pz * pz;
@@ -231,40 +229,52 @@ void build_filter_arrays(PackedScene &out)
         const double c[3] = {s.x, s.y, s.z};
         entry(c, (double)s.w, &out.sph_f[i]);
     }
-    // Bounding balls: centre = middle of the members' extent, rounded the way the filter will
-    // see it; radius = max over members of |centre_i - centre| + r_i against that rounded
-    // centre, widened by 1e-6 relative.
-    for (size_t g = 0; g < n / RT_GROUP; g++) {
-        double blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        bool any = false;
-        for (size_t i = g * RT_GROUP; i < (g + 1) * RT_GROUP; i++) {
-            if (out.sph_f[i].w == -INFINITY) continue;
-            const float4 &s = out.sph[i];
-            const double c[3] = {s.x, s.y, s.z}, r = std::sqrt((double)s.w);
-            for (int k = 0; k < 3; k++) blo[k] = std::min(blo[k], c[k] - r), bhi[k] = std::max(bhi[k], c[k] + r);
-            any = true;
+    // Bounding balls of every aligned run of `run` spheres: centre = middle of the members'
+    // extent, rounded the way the filter will see it; radius = max over members of
+    // |centre_i - centre| + r_i against that rounded centre, widened by 1e-6 relative.  The
+    // array is padded with never-pass entries to a multiple of `pad` balls.
+    auto balls = [&](size_t run, size_t pad, std::vector<float4> &dst, double &rmax) {
+        const size_t nb = (n + run - 1) / run;
+        dst.assign((nb + pad - 1) / pad * pad, never);
+        for (size_t g = 0; g < nb; g++) {
+            const size_t i0 = g * run, i1 = std::min(n, (g + 1) * run);
+            double blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            bool any = false;
+            for (size_t i = i0; i < i1; i++) {
+                if (out.sph_f[i].w == -INFINITY) continue;
+                const float4 &s = out.sph[i];
+                const double c[3] = {s.x, s.y, s.z}, r = std::sqrt((double)s.w);
+                for (int k = 0; k < 3; k++) blo[k] = std::min(blo[k], c[k] - r), bhi[k] = std::max(bhi[k], c[k] + r);
+                any = true;
+            }
+            if (!any) continue;
+            double bc[3];
+            for (int k = 0; k < 3; k++) bc[k] = (double)(float)(0.5 * (blo[k] + bhi[k]) - cen[k]) + cen[k];
+            double rad = 0.0;
+            for (size_t i = i0; i < i1; i++) {
+                if (out.sph_f[i].w == -INFINITY) continue;
+                const float4 &s = out.sph[i];
+                const double dx = s.x - bc[0], dy = s.y - bc[1], dz = s.z - bc[2];
+                rad = std::max(rad, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)s.w));
+            }
+            rad *= 1.0 + 1e-6;
+            if (entry(bc, rad * rad, &dst[g])) rmax = std::max(rmax, rad);
+            else {
+                // The ball cannot be represented: keep its members reachable with an always-pass ball.
+                dst[g] = make_float4(0.f, 0.f, 0.f, INFINITY);
+            }
         }
-        if (!any) continue;
-        double bc[3];
-        for (int k = 0; k < 3; k++) bc[k] = (double)(float)(0.5 * (blo[k] + bhi[k]) - cen[k]) + cen[k];
-        double rad = 0.0;
-        for (size_t i = g * RT_GROUP; i < (g + 1) * RT_GROUP; i++) {
-            if (out.sph_f[i].w == -INFINITY) continue;
-            const float4 &s = out.sph[i];
-            const double dx = s.x - bc[0], dy = s.y - bc[1], dz = s.z - bc[2];
-            rad = std::max(rad, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)s.w));
-        }
-        rad *= 1.0 + 1e-6;
-        if (entry(bc, rad * rad, &out.grp_f[g])) grmax = std::max(grmax, rad);
-        else {
-            // The ball cannot be represented: keep its members reachable with an always-pass ball.
-            out.grp_f[g] = make_float4(0.f, 0.f, 0.f, INFINITY);
-        }
-    }
+    };
+    double grmax = 0.0, surmax = 0.0, chrmax = 0.0;
+    balls(RT_GROUP, 1, out.grp_f, grmax);
+    balls(RT_SUPER, 8, out.sup_f, surmax);
+    balls(RT_CHUNK, 8, out.chk_f, chrmax);
     const double up = 1.0 + 1e-6;   // far above the single rounding to float
     out.sph_l1max = (float)(l1max * up);
     out.sph_sc = (float)((2.0 * p2max + r2max) * up);
     out.grp_rmax = (float)(grmax * up);
+    out.sup_rmax = (float)(surmax * up);
+    out.chk_rmax = (float)(chrmax * up);
 }
 
 int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
@@ -350,6 +360,7 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     HIP_TRY(ctx, hipStreamSynchronize(d.stream));
     free_scene(d);
     DevScene &sc = d.scene;
+    d.resident_blocks = 0;
     sc.ns_padded = (int)ps.sph.size();
     sc.ns = ps.class_prefix[3 * (size_t)n];
     sc.np = (int)ps.pl.size();
@@ -360,6 +371,8 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     if ((rc = upload(ctx, d, ps.sph, &sc.sph)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.sph_f, &sc.sph_f)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.grp_f, &sc.grp_f)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.sup_f, &sc.sup_f)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.chk_f, &sc.chk_f)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.sph_orig, &sc.sph_orig)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.pl, &sc.pl)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.pl_orig, &sc.pl_orig)) != RT_OK) return rc;
@@ -370,11 +383,17 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     if ((rc = upload(ctx, d, ps.light_pos, &sc.light_pos)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.light_col, &sc.light_col)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.class_prefix, &sc.class_prefix)) != RT_OK) return rc;
-    HIP_TRY(ctx, hipMalloc((void **)&d.sph_cam, std::max<size_t>(ps.sph.size() * sizeof(float4), 16)));
-    HIP_TRY(ctx, hipMalloc((void **)&d.grp_cam, std::max<size_t>(ps.grp_f.size() * sizeof(float4), 16)));
-    sc.sph_cam = d.sph_cam;
-    sc.grp_cam = d.grp_cam;
+    const size_t cam_entries = ps.sph.size() + ps.grp_f.size() + ps.sup_f.size() + ps.chk_f.size();
+    HIP_TRY(ctx, hipMalloc((void **)&d.cam_terms, std::max<size_t>(cam_entries * sizeof(float4), 16)));
+    sc.sph_cam = d.cam_terms;
+    sc.grp_cam = sc.sph_cam + ps.sph.size();
+    sc.sup_cam = sc.grp_cam + ps.grp_f.size();
+    sc.chk_cam = sc.sup_cam + ps.sup_f.size();
+    sc.nsup_padded = (int)ps.sup_f.size();
+    sc.nchk_padded = (int)ps.chk_f.size();
     sc.grp_rmax = ps.grp_rmax;
+    sc.sup_rmax = ps.sup_rmax;
+    sc.chk_rmax = ps.chk_rmax;
     for (int k = 0; k < 3; k++) sc.sph_center[k] = ps.sph_center[k];
     sc.sph_l1max = ps.sph_l1max;
     sc.sph_sc = ps.sph_sc;
@@ -519,7 +538,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     d.timed = ctx->profiling && stream == d.stream;
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
     const int blocks = std::max(1, std::min({(P + 255) / 256, d.num_cus * 8, RT_COUNTER_SLOTS}));
-    rtk_setup_camera(d.scene, dc, d.sph_cam, d.grp_cam, stream);
+    rtk_setup_camera(d.scene, dc, stream);
     rtk_primary(d.scene, dc, f, dev_pixels, blocks, stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[1], stream));
     // RT_HIP_LEVEL_KERNELS=1 (profiling aid): one launch per queue per level on this stream,
@@ -532,10 +551,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
         }
     } else {
         // Every level in one launch of resident workgroups (k_trace_levels).
-        if (d.resident_nl != d.scene.nl) {
-            d.resident_blocks = rtk_trace_levels_resident_blocks(d.scene.nl, d.num_cus);
-            d.resident_nl = d.scene.nl;
-        }
+        if (d.resident_blocks <= 0) d.resident_blocks = rtk_trace_levels_resident_blocks(d.scene, d.num_cus);
         const int tiles0 = (P + 255) / 256;
         rtk_trace_levels(d.scene, f, std::max(1, std::min({2 * tiles0, d.resident_blocks, RT_COUNTER_SLOTS})), stream);
     }

@@ -11,7 +11,10 @@
 //   sph_f    float4 {p'x, p'y, p'z, W}       the sphere filter's view of the same spheres:
 //                                            p' = centre - sph_center, W = r*r - k1*|p'|^2
 //   grp_f    float4 {P'x, P'y, P'z, W}       one bounding ball per group, same form
-//   sph_cam, grp_cam  float4 {p', -c''}      per frame: the filter's term for the camera origin
+//   sup_f, chk_f                             one bounding ball per RT_SUPER (64) spheres and per
+//                                            RT_CHUNK (1024) spheres: two coarser levels, same form
+//   sph_cam, grp_cam, sup_cam, chk_cam  float4 {p', -c''}  per frame: the filter's term for the
+//                                            camera origin
 //   pl       float4 {nx, ny, nz, d}          one per plane
 //   tri      float4 x3 {v0}, {e1}, {e2}      e1 = v1-v0, e2 = v2-v0 (objects.cs:238-239)
 //   geo      float4 per host primitive: sphere centre or plane/triangle normal
@@ -39,6 +42,8 @@
 // the sphere filter, and so are the balls of groups made of padding only.
 #define RT_GROUP 8
 #define RT_SPH_PAD (RT_GROUP * 8)
+#define RT_SUPER RT_SPH_PAD   // spheres per ball of the second level = groups of one GROUP-loop trip
+#define RT_CHUNK 1024         // spheres staged in LDS at a time; one ball of the third level each
 // k1 = 1 - 2^-18, the filter's relative margin (shared by the host's W and the kernels).
 #define RT_FILTER_K1 0.999996185302734375f
 
@@ -48,12 +53,20 @@ struct DevScene {
     float sph_center[3];      // the filter's coordinate origin (centre of the spheres' bounding box)
     float sph_l1max;          // >= max over spheres of |p'|_1
     float sph_sc;             // >= 2 max |p'|^2 + max r*r   (p', r over spheres and balls)
-    float grp_rmax;           // >= the largest bounding-ball radius
+    float grp_rmax;           // >= the largest bounding-ball radius of a group,
+    float sup_rmax;           //    of a run of RT_SUPER spheres,
+    float chk_rmax;           //    of a chunk
+    int nsup_padded;          // entries of sup_f: ns_padded / RT_SUPER rounded up to a multiple of 8
+    int nchk_padded;          // entries of chk_f: chunks rounded up to a multiple of 8
     const float4 *sph;
     const float4 *sph_f;
     const float4 *grp_f;      // ns_padded / RT_GROUP bounding balls
+    const float4 *sup_f;      // nsup_padded balls (padding: never-pass entries)
+    const float4 *chk_f;      // nchk_padded balls
     const float4 *sph_cam;    // per frame: {p', filter term} for the camera origin
     const float4 *grp_cam;
+    const float4 *sup_cam;
+    const float4 *chk_cam;
     const int *sph_orig;
     const float4 *pl;
     const int *pl_orig;
@@ -143,8 +156,8 @@ struct DevFrame {
 };
 
 // Launch wrappers (rt_kernels.hip).  All enqueue on `stream` and return at once.
-void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, float4 *grp_cam,
-                      hipStream_t stream);
+// Fills the *_cam arrays of the scene (writable views of the same pointers).
+void rtk_setup_camera(const DevScene &s, const DevCamera &cam, hipStream_t stream);
 void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels,
                  int grid_blocks, hipStream_t stream);
 // reflecting: the level's records that need a reflection trace (queue A) or the others (B).
@@ -152,7 +165,7 @@ void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting,
                hipStream_t stream);
 // Every level in one launch; grid_blocks = workgroups resident at once on the device
 // (rtk_trace_levels_resident_blocks), fewer if the frame has fewer tiles.
-int rtk_trace_levels_resident_blocks(int nl, int num_cus);
+int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus);
 void rtk_trace_levels(const DevScene &s, const DevFrame &f, int grid_blocks, hipStream_t stream);
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
                      int grid_blocks, hipStream_t stream);

@@ -206,6 +206,56 @@ __device__ __forceinline__ void store_record(float4 *dst, const f4raw v)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
 }
 
+// The rays of a hit record are traced in one or more WALKS of the scene, each a job of its own
+// for the level schedule: at most LCMAX rays per walk, where LCMAX = 4 in scenes with four or
+// more lights and 2 otherwise (with few lights the two-ray instance needs far fewer registers
+// and its rays are close enough to share one selection of spheres).  Walk 0 of a reflecting
+// record carries the reflection ray and its first LCMAX - 1 lights (LCMAX 2: both lights, three
+// rays); the other walks take the remaining lights in aligned groups of LCMAX, after one short
+// walk up to the first multiple of LCMAX if need be.  A walk's lights never straddle a 32-bit
+// word of the occlusion mask.
+__host__ __device__ __forceinline__ int walk_lcmax(int nl) { return nl >= 4 ? 4 : 2; }
+__host__ __device__ __forceinline__ int walk_first_lights(int lcmax) { return lcmax >= 4 ? 3 : 2; }
+__host__ __device__ __forceinline__ int walks_of(bool reflecting, int nl)
+{
+    const int g = walk_lcmax(nl), f = walk_first_lights(g);
+    if (!reflecting) return (nl + g - 1) / g;
+    if (nl <= f) return 1;
+    const int a0 = (f + g - 1) / g * g;
+    return 1 + (a0 > f ? 1 : 0) + (nl > a0 ? (nl - a0 + g - 1) / g : 0);
+}
+__device__ __forceinline__ void walk_lights(bool reflecting, int walk, int nl, int &l0, int &count)
+{
+    const int g = walk_lcmax(nl), f = walk_first_lights(g);
+    if (!reflecting) {
+        l0 = walk * g;
+        count = min(g, nl - l0);
+        return;
+    }
+    if (walk == 0) {
+        l0 = 0;
+        count = min(f, nl);
+        return;
+    }
+    const int a0 = (f + g - 1) / g * g;
+    if (a0 > f) {
+        if (walk == 1) {
+            l0 = f;
+            count = min(a0, nl) - f;
+            return;
+        }
+        walk--;
+    }
+    l0 = a0 + (walk - 1) * g;
+    count = min(g, nl - l0);
+}
+
+// A 32-bit word to memory with a device-scope store, like store_record.
+__device__ __forceinline__ void store_word_through(uint32_t *dst, uint32_t v)
+{
+    asm volatile("global_store_dword %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+}
+
 // Append up to N new hit records per thread to level `level`, with ONE atomic per queue per
 // WORKGROUP: a single counter word takes only ~90 returning atomics per microsecond, and a
 // frame appends hundreds of thousands of waves' worth of records.  Every thread of the
@@ -256,6 +306,9 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
             const int slot = is_a[k] ? (level * f.P + base_a + off[k]) : ((level + 1) * f.P - 1 - (base_b + off[k]));
             store_record(&f.recA[slot], f4raw{hit[k].x, hit[k].y, hit[k].z, __int_as_float(prim[k])});
             store_record(&f.recB[slot], f4raw{view[k].x, view[k].y, view[k].z, __int_as_float(parent[k])});
+            // Several walks OR their lights into the record's occlusion words: start from zero.
+            if (walks_of(is_a[k], s.nl) > 1)
+                for (int w = 0; w < f.mask_words; w++) store_word_through(&f.mask[(size_t)w * (size_t)f.slots + slot], 0u);
         }
     }
     __syncthreads();  // blk may be reused by the caller's next trip
@@ -319,7 +372,9 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
 // ---------------------------------------------------------------------------------------
 struct FilterOrigin {
     f4raw lane;     // (Bx, By, Bz, C0): the sphere loops' per-origin operand
-    f4raw lane_g;   // (Bx, By, Bz, C0 of the bounding balls)
+    f4raw lane_g;   // (Bx, By, Bz, C0 of the groups' bounding balls),
+    f4raw lane_s;   //   ... of the balls around RT_SUPER spheres,
+    f4raw lane_c;   //   ... of the chunks' balls
     f3 oc;          // o' = o - centre
     float fm;       // front margin
 };
@@ -336,7 +391,11 @@ __device__ __forceinline__ FilterOrigin filter_origin(const DevScene &s, f3 o)
     // Balls: radius widened by sg (see "Bounding balls" above): E_g = E + 2*Rmax*sg + sg^2.
     const float sg = FILTER_BALL_SLACK * (((fabsf(fo.oc.x) + fabsf(fo.oc.y)) + fabsf(fo.oc.z)) + s.sph_l1max);
     const float eg = e + __builtin_fmaf(2.0f * s.grp_rmax, sg, sg * sg);
+    const float es = e + __builtin_fmaf(2.0f * s.sup_rmax, sg, sg * sg);
+    const float ec = e + __builtin_fmaf(2.0f * s.chk_rmax, sg, sg * sg);
     fo.lane_g = f4raw{fo.lane.x, fo.lane.y, fo.lane.z, (FILTER_K1 * oo) - eg};
+    fo.lane_s = f4raw{fo.lane.x, fo.lane.y, fo.lane.z, (FILTER_K1 * oo) - es};
+    fo.lane_c = f4raw{fo.lane.x, fo.lane.y, fo.lane.z, (FILTER_K1 * oo) - ec};
     return fo;
 }
 
@@ -349,22 +408,25 @@ __device__ __forceinline__ f4raw filter_ray(const FilterOrigin &fo, f3 d)
 
 // ---------------------------------------------------------------------------------------
 // setup_camera: every primary ray starts at camera.position, so the filter's per-entry
-// term -c'' for that origin is computed once per frame for spheres and bounding balls:
-// sph_cam[i] = {p', -c''}, grp_cam[g] = {P', -c''_g}.
+// term -c'' for that origin is computed once per frame for spheres and bounding balls of all
+// three levels: sph_cam[i] = {p', -c''}, grp_cam[g] = {P', -c''_g}, likewise sup_cam, chk_cam
+// (ns_padded >= 64 whenever there is a sphere, and the coarse arrays have at most that many entries).
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam, float4 *sph_cam, float4 *grp_cam)
+__device__ __forceinline__ float4 camera_term(const float4 pf, const f4raw lane)
+{
+    const float chain = __builtin_fmaf(lane.x, pf.x, __builtin_fmaf(lane.y, pf.y, __builtin_fmaf(lane.z, pf.z, pf.w)));
+    return make_float4(pf.x, pf.y, pf.z, chain - lane.w);   // padding: -inf, never passes
+}
+
+__global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.ns_padded) return;
     const FilterOrigin fo = filter_origin(s, mk3(cam.pos[0], cam.pos[1], cam.pos[2]));
-    const float4 pf = s.sph_f[i];
-    const float chain = __builtin_fmaf(fo.lane.x, pf.x, __builtin_fmaf(fo.lane.y, pf.y, __builtin_fmaf(fo.lane.z, pf.z, pf.w)));
-    sph_cam[i] = make_float4(pf.x, pf.y, pf.z, chain - fo.lane.w);   // padding: -inf, never passes
-    if (i < s.ns_padded / RT_GROUP) {
-        const float4 gf = s.grp_f[i];
-        const float gchain = __builtin_fmaf(fo.lane.x, gf.x, __builtin_fmaf(fo.lane.y, gf.y, __builtin_fmaf(fo.lane.z, gf.z, gf.w)));
-        grp_cam[i] = make_float4(gf.x, gf.y, gf.z, gchain - fo.lane_g.w);
-    }
+    const_cast<float4 *>(s.sph_cam)[i] = camera_term(s.sph_f[i], fo.lane);
+    if (i < s.ns_padded / RT_GROUP) const_cast<float4 *>(s.grp_cam)[i] = camera_term(s.grp_f[i], fo.lane_g);
+    if (i < s.nsup_padded) const_cast<float4 *>(s.sup_cam)[i] = camera_term(s.sup_f[i], fo.lane_s);
+    if (i < s.nchk_padded) const_cast<float4 *>(s.chk_cam)[i] = camera_term(s.chk_f[i], fo.lane_c);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -376,12 +438,16 @@ __global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam,
 // may hit (lanes queue one word per trip with a candidate), and then evaluates each lane's
 // (short) queue exactly here in C++.
 
-// Staged per workgroup: a chunk of SPH_CHUNK filter entries {p', W} (or, for the primary
-// kernel, {p', -c''}) and its SPH_CHUNK / RT_GROUP bounding balls plus FA_LDS_SLACK never-pass
-// entries for the GROUP loops' read-ahead.
-#define SPH_CHUNK 1024
+// Staged per workgroup (WalkLds): a chunk of SPH_CHUNK filter entries {p', W} (or, for the
+// primary kernel, {p', -c''}), the bounding balls of its groups and of its runs of RT_SUPER
+// spheres, each array followed by FA_LDS_SLACK never-pass entries for the GROUP loops'
+// read-ahead.  Scenes with more than one chunk also stage the chunks' own balls, GRP_CHUNK at a
+// time, in the groups' array before they walk the chunks those select.
+#define SPH_CHUNK RT_CHUNK
 #define GRP_CHUNK (SPH_CHUNK / RT_GROUP)
 #define GRP_LDS_ENTRIES (GRP_CHUNK + FA_LDS_SLACK)
+#define SUP_CHUNK (SPH_CHUNK / RT_SUPER)
+#define SUP_LDS_ENTRIES (SUP_CHUNK + FA_LDS_SLACK)
 #define GRP_WORDS (GRP_CHUNK / 32)
 // Queues: QUEUE_SLOTS words per thread, slot-major (slot s of thread t at int index 256*s + t).
 // GROUP loops leave trip j's reject mask (ball m of the trip = bit 7-m, 0 = could hit) in
@@ -393,6 +459,16 @@ __global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam,
 #define QUEUE_INTS (QUEUE_SLOTS * 256)
 static_assert(GRP_CHUNK / FA_TRIP <= QUEUE_SLOTS, "one queue slot per trip of balls");
 static_assert(RT_GROUP == FA_TRIP && RT_SPH_PAD == FA_TRIP * RT_GROUP, "a trip of a SEL loop is one group");
+static_assert(RT_SUPER == FA_TRIP * RT_GROUP, "a trip of a GROUP loop over the groups' balls is one coarse ball");
+static_assert(SUP_CHUNK % FA_TRIP == 0, "the coarse balls of a full chunk are whole trips");
+
+struct WalkLds {
+    float4 sph[SPH_CHUNK];
+    float4 grp[GRP_LDS_ENTRIES];
+    float4 sup[SUP_LDS_ENTRIES];
+    int cand[QUEUE_INTS];
+    unsigned wg_bits[GRP_WORDS];   // chunks some wave of the workgroup has to walk
+};
 
 // Walks a thread's queued words: next() returns the next sphere index (local to the staged
 // chunk) the lane has to evaluate exactly, or -1 when its queue is exhausted.
@@ -416,13 +492,26 @@ struct CandidateWalk {
     }
 };
 
-__device__ __forceinline__ void stage_chunk(float4 *lds, float4 *ldg, const float4 *sph_src, const float4 *grp_src,
-                                            int base, int count)
+// Filter entries of spheres [base, base + count) and their balls (count: a multiple of RT_SUPER).
+__device__ __forceinline__ void stage_chunk(WalkLds &L, const float4 *sph_src, const float4 *grp_src,
+                                            const float4 *sup_src, int base, int count)
 {
-    for (int i = threadIdx.x; i < count; i += blockDim.x) lds[i] = sph_src[base + i];
+    const float4 never = make_float4(0.f, 0.f, 0.f, -INFINITY);
+    for (int i = threadIdx.x; i < count; i += blockDim.x) L.sph[i] = sph_src[base + i];
     const int ng = count / RT_GROUP;
-    for (int i = threadIdx.x; i < ng; i += blockDim.x) ldg[i] = grp_src[base / RT_GROUP + i];
-    if (threadIdx.x < FA_LDS_SLACK) ldg[ng + threadIdx.x] = make_float4(0.f, 0.f, 0.f, -INFINITY);
+    for (int i = threadIdx.x; i < ng; i += blockDim.x) L.grp[i] = grp_src[base / RT_GROUP + i];
+    if (threadIdx.x < FA_LDS_SLACK) L.grp[ng + threadIdx.x] = never;
+    // Coarse balls: padded to whole trips (the source array is padded the same way).
+    const int ns = count / RT_SUPER;
+    if ((int)threadIdx.x < SUP_LDS_ENTRIES) L.sup[threadIdx.x] = (int)threadIdx.x < ns ? sup_src[base / RT_SUPER + threadIdx.x] : never;
+}
+
+// Balls [first, first + count) of the chunks (count: a multiple of FA_TRIP, at most GRP_CHUNK).
+__device__ __forceinline__ void stage_chunk_balls(WalkLds &L, const float4 *chk_src, int first, int count)
+{
+    for (int i = threadIdx.x; i < count + FA_LDS_SLACK; i += blockDim.x)
+        L.grp[i] = i < count ? chk_src[first + i] : make_float4(0.f, 0.f, 0.f, -INFINITY);
+    if (threadIdx.x < GRP_WORDS) L.wg_bits[threadIdx.x] = 0u;
 }
 
 // Byte offset of an LDS object inside the workgroup's LDS allocation (what ds_read takes).
@@ -477,6 +566,35 @@ __device__ __forceinline__ void fa_group(int &i, unsigned &addr, unsigned &qaddr
         if constexpr (K == 3) FA_RUN(FA_GROUPS3, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_LANE(lane));
         if constexpr (K == 4)
             FA_RUN(FA_GROUPS4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_LANE(lane));
+    }
+#undef FA_RUN
+}
+
+// GSEL loop: the trips of the ball array at LDS offset addr0 that the bitmap names (bit b of wlo =
+// trip b ^ 7), masks stored like a GROUP loop's (slot s of the lane at qaddr0 + s * FA_QUEUE_STRIDE).
+template <int K, bool TRACE, bool SPLIT>
+__device__ __forceinline__ void fa_gsel(unsigned long long wlo, const unsigned qaddr0, const f4raw (&rq)[4],
+                                        const f4raw lane, const unsigned addr0)
+{
+    unsigned long long whi = 0ull;
+    int trip0 = 0;
+#define FA_RUN(NAME, ...)                                                    \
+    asm volatile(NAME##_ASM                                                  \
+                 : [wlo] "+s"(wlo), [whi] "+s"(whi), [trip0] "+s"(trip0)     \
+                 : __VA_ARGS__, [qaddr] "v"(qaddr0), [addr0] "s"(addr0)      \
+                 : NAME##_CLOBBERS)
+    if constexpr (!TRACE) {
+        FA_RUN(FA_PGSEL4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]));
+    } else if constexpr (K == 1) {
+        FA_RUN(FA_GSEL1, FA_DN0(rq[0]), FA_LANE(lane));
+    } else if constexpr (!SPLIT) {
+        if constexpr (K == 2) FA_RUN(FA_GSEL2, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_LANE(lane));
+        if constexpr (K == 3) FA_RUN(FA_GSEL3, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_LANE(lane));
+    } else {
+        if constexpr (K == 2) FA_RUN(FA_GSELS2, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_LANE(lane));
+        if constexpr (K == 3) FA_RUN(FA_GSELS3, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_LANE(lane));
+        if constexpr (K == 4)
+            FA_RUN(FA_GSELS4, FA_DN0(rq[0]), FA_DN1(rq[1]), FA_DN2(rq[2]), FA_DN3(rq[3]), FA_LANE(lane));
     }
 #undef FA_RUN
 }
@@ -538,18 +656,19 @@ struct RayIndex {
 // lane's queued candidates: exact(sphere {centre, r*r}, host index), EXACT_BATCH candidates per
 // lane at a time with their data fetched together.  Returns the trips run.
 template <int K, bool TRACE, class Exact>
-__device__ __forceinline__ int run_selected(const float4 *lds, int *cand, const float4 *sph, const int *orig,
+__device__ __forceinline__ int run_selected(WalkLds &L, const float4 *sph, const int *orig,
                                             const f4raw (&rq)[4], const f4raw lane, unsigned long long wlo,
                                             unsigned long long whi, int &candidates, PhaseClock &pc, Exact &&exact)
 {
-    const unsigned q0 = lds_offset(cand) + 4u * threadIdx.x;
-    const unsigned qlim = lds_offset(cand) + QUEUE_SLOTS * FA_QUEUE_STRIDE;
+    const int *cand = L.cand;
+    const unsigned q0 = lds_offset(L.cand) + 4u * threadIdx.x;
+    const unsigned qlim = lds_offset(L.cand) + QUEUE_SLOTS * FA_QUEUE_STRIDE;
     int trip0 = 0, trips = 0;
 #pragma clang loop unroll(disable)
     while ((wlo | whi) != 0ull) {
         unsigned qaddr = q0;
         trips += __popcll(wlo) + __popcll(whi);
-        fa_sel<K, TRACE>(wlo, whi, trip0, qaddr, rq, lane, lds_offset(lds), qlim);
+        fa_sel<K, TRACE>(wlo, whi, trip0, qaddr, rq, lane, lds_offset(L.sph), qlim);
         trips -= __popcll(wlo) + __popcll(whi);   // what a full queue left for the next call
         PHASE_MARK(pc, 4)
         CandidateWalk walk(cand, (int)((qaddr - q0) / FA_QUEUE_STRIDE));
@@ -582,43 +701,14 @@ __device__ __forceinline__ int run_selected(const float4 *lds, int *cand, const 
     return trips;
 }
 
-// One staged chunk of `cnt` spheres (a multiple of RT_SPH_PAD) for K rays per lane: a GROUP
-// loop over the chunk's bounding balls, the lanes' pass bits ORed over the wave, SEL loops over
-// the groups some lane may hit, the exact evaluation of what they queue.
-//   SPLIT false: one bitmap for the K rays of a lane; exact(RayIndex<-1>, sphere, host index)
-//     evaluates all of them.  Right when the rays are close to each other: the four pixels of
-//     a primary lane, the two or three rays of a record in a scene with two lights.
-//   SPLIT true (trace rays): with more lights the rays of a record point in unrelated
-//     directions, so every ray k has its own bitmap and runs only the groups IT may hit, one
-//     ray per SEL loop; exact(RayIndex<k>, sphere, host index) evaluates ray k.
-// The sphere's {centre, r*r} and host primitive index come from sph / orig (the chunk's part of
-// DevScene::sph / sph_orig).  The order of the calls is not the spheres' host order.  Every lane
-// of the wave must be active.
-template <int K, bool TRACE, bool SPLIT, class Exact>
-__device__ __forceinline__ void walk_chunk(const float4 *lds, const float4 *ldg, int *cand, const int cnt,
-                                           const float4 *sph, const int *orig, const f4raw (&rq)[4],
-                                           const f4raw lane_g, const f4raw lane, FilterWork &fw, PhaseClock &pc,
-                                           Exact &&exact)
+// The wave-wide pass bits of the first `ntrips` trips a GROUP loop left in the queue slots
+// (bit 8t + b of word w = entry 8(4w + t) + 7 - b of the array the loop walked), one bitmap
+// per ray when the loop kept the rays apart (NB = K), else one for all (NB = 1).
+template <int NB, int NW>
+__device__ __forceinline__ void gather_pass_bits(const int *cand, const int ntrips, unsigned (&words)[NB][NW])
 {
-    static_assert(TRACE || !SPLIT, "primary rays use the combined loops");
-    constexpr bool split = SPLIT && K > 1;
-    const int ngroups = cnt / RT_GROUP, ntrips = ngroups / FA_TRIP;
-    PHASE_MARK(pc, 1)
-    {
-        int i = 0;
-        unsigned addr = lds_offset(ldg), qaddr = lds_offset(cand) + 4u * threadIdx.x;
-        fa_group<K, TRACE, split>(i, addr, qaddr, rq, lane_g, ngroups);
-        fw.terms += TRACE ? ntrips * FA_TRIP : 0;
-        fw.ray_tests += ntrips * FA_TRIP * K;
-    }
-    PHASE_MARK(pc, 2)
-    // Pass bits of 32 groups per word (bit 8t + b = group 8(4*word + t) + 7 - b), wave-wide,
-    // one bitmap per ray (split) or one for all.
-    static_assert(GRP_WORDS == 4, "the bitmap of a chunk is two 64-bit halves");
-    constexpr int NB = split ? K : 1;
-    unsigned words[NB][GRP_WORDS];
 #pragma unroll
-    for (int wd = 0; wd < GRP_WORDS; wd++) {
+    for (int wd = 0; wd < NW; wd++) {
         unsigned bits[NB];
 #pragma unroll
         for (int k = 0; k < NB; k++) bits[k] = 0u;
@@ -634,9 +724,69 @@ __device__ __forceinline__ void walk_chunk(const float4 *lds, const float4 *ldg,
 #pragma unroll
         for (int k = 0; k < NB; k++) words[k][wd] = wave_or(bits[k]);
     }
+}
+
+// One staged chunk of `cnt` spheres (a multiple of RT_SPH_PAD) for K rays per lane, three levels
+// of conservative tests, each deciding per WAVE what the next one looks at:
+//   1. a GROUP loop over the balls around runs of RT_SUPER spheres (at most two trips);
+//   2. GROUP-loop trips over the groups' balls, only for the runs some lane's ray may hit (one
+//      trip = the FA_TRIP groups of one run);
+//   3. SEL loops over the spheres of the groups some lane may hit, which queue candidates, and
+//      the exact evaluation of each lane's queue.
+//   SPLIT false: one bitmap for the K rays of a lane; exact(RayIndex<-1>, sphere, host index)
+//     evaluates all of them.  Right when the rays are close to each other: the four pixels of
+//     a primary lane, the two or three rays of a record in a scene with two lights.
+//   SPLIT true (trace rays): with more lights the rays of a record point in unrelated
+//     directions, so at level 3 every ray k has its own bitmap and runs only the groups IT may
+//     hit, one ray per SEL loop; exact(RayIndex<k>, sphere, host index) evaluates ray k.
+// lane_s / lane_g: the per-origin operands of the two ball levels (trace rays).  The sphere's
+// {centre, r*r} and host primitive index come from sph / orig (the chunk's part of
+// DevScene::sph / sph_orig).  The order of the calls is not the spheres' host order.  Every lane
+// of the wave must be active.
+template <int K, bool TRACE, bool SPLIT, class Exact>
+__device__ __forceinline__ void walk_chunk(WalkLds &L, const int cnt, const float4 *sph, const int *orig,
+                                           const f4raw (&rq)[4], const f4raw lane_s, const f4raw lane_g,
+                                           const f4raw lane, FilterWork &fw, PhaseClock &pc, Exact &&exact)
+{
+    static_assert(TRACE || !SPLIT, "primary rays use the combined loops");
+    constexpr bool split = SPLIT && K > 1;
+    constexpr int NB = split ? K : 1;
+    const int ngroups = cnt / RT_GROUP, ntrips = ngroups / FA_TRIP;
+    const unsigned q0 = lds_offset(L.cand) + 4u * threadIdx.x;
+    PHASE_MARK(pc, 1)
+    // Level 1: which runs of RT_SUPER spheres (= which trips of level 2) can any ray of the wave hit?
+    unsigned runs;
+    {
+        const int nsup = (ntrips + FA_TRIP - 1) / FA_TRIP * FA_TRIP;   // staged padded to whole trips
+        int i = 0;
+        unsigned addr = lds_offset(L.sup), qaddr = q0;
+        fa_group<K, TRACE, split>(i, addr, qaddr, rq, lane_s, nsup);
+        fw.terms += TRACE ? nsup : 0;
+        fw.ray_tests += nsup * K;
+        unsigned any[NB][1];
+        gather_pass_bits<NB, 1>(L.cand, nsup / FA_TRIP, any);
+        runs = 0u;
+#pragma unroll
+        for (int k = 0; k < NB; k++) runs |= any[k][0];   // bit 8t + 7 - m = run 8t + m
+    }
+    // Level 2: the groups' balls of those runs; the slots of the other trips read "all rejected".
+#pragma unroll
+    for (int j = 0; j < SUP_CHUNK; j++)
+        if (j < ntrips) L.cand[j * 256 + threadIdx.x] = -1;
+    if (runs != 0u) {
+        fa_gsel<K, TRACE, split>((unsigned long long)runs, q0, rq, lane_g, lds_offset(L.grp));
+        const int ran = __popc(runs);
+        fw.terms += TRACE ? ran * FA_TRIP : 0;
+        fw.ray_tests += ran * FA_TRIP * K;
+    }
+    PHASE_MARK(pc, 2)
+    static_assert(GRP_WORDS == 4, "the bitmap of a chunk is two 64-bit halves");
+    unsigned words[NB][GRP_WORDS];
+    gather_pass_bits<NB, GRP_WORDS>(L.cand, ntrips, words);
     PHASE_MARK(pc, 3)
+    // Level 3.
     if constexpr (!split) {
-        const int trips = run_selected<K, TRACE>(lds, cand, sph, orig, rq, lane,
+        const int trips = run_selected<K, TRACE>(L, sph, orig, rq, lane,
                                                  (unsigned long long)words[0][0] | ((unsigned long long)words[0][1] << 32),
                                                  (unsigned long long)words[0][2] | ((unsigned long long)words[0][3] << 32),
                                                  fw.candidates, pc,
@@ -649,7 +799,7 @@ __device__ __forceinline__ void walk_chunk(const float4 *lds, const float4 *ldg,
             constexpr int k = decltype(kc)::value;
             if constexpr (k < K) {
                 const f4raw one[4] = {rq[k], rq[k], rq[k], rq[k]};
-                trips += run_selected<1, true>(lds, cand, sph, orig, one, lane,
+                trips += run_selected<1, true>(L, sph, orig, one, lane,
                                                (unsigned long long)words[k][0] | ((unsigned long long)words[k][1] << 32),
                                                (unsigned long long)words[k][2] | ((unsigned long long)words[k][3] << 32),
                                                fw.candidates, pc,
@@ -662,6 +812,52 @@ __device__ __forceinline__ void walk_chunk(const float4 *lds, const float4 *ldg,
         one_ray(RayIndex<3>());
         fw.terms += trips * FA_TRIP;
         fw.ray_tests += trips * FA_TRIP;
+    }
+}
+
+// The chunks of a scene with more than one: `visit(base, cnt)` is called, by the whole
+// workgroup, for every chunk whose ball some ray of some wave may hit (the chunks' balls are
+// tested GRP_CHUNK at a time with a GROUP loop, and the waves' pass bits are ORed in LDS because
+// staging a chunk is the workgroup's business).  Every thread of the workgroup must call it.
+template <int K, bool TRACE, bool SPLIT, class Visit>
+__device__ __forceinline__ void for_each_chunk(WalkLds &L, const int nsp, const int nchk_padded, const float4 *chk_src,
+                                               const f4raw (&rq)[4], const f4raw lane_c, FilterWork &fw, Visit &&visit)
+{
+    constexpr bool split = SPLIT && K > 1;
+    constexpr int NB = split ? K : 1;
+    for (int first = 0; first < nchk_padded; first += GRP_CHUNK) {
+        const int n = min(GRP_CHUNK, nchk_padded - first);
+        __syncthreads();   // whoever still reads the staged arrays is done
+        stage_chunk_balls(L, chk_src, first, n);
+        __syncthreads();
+        int i = 0;
+        unsigned addr = lds_offset(L.grp), qaddr = lds_offset(L.cand) + 4u * threadIdx.x;
+        fa_group<K, TRACE, split>(i, addr, qaddr, rq, lane_c, n);
+        fw.terms += TRACE ? n : 0;
+        fw.ray_tests += n * K;
+        unsigned words[NB][GRP_WORDS];
+        gather_pass_bits<NB, GRP_WORDS>(L.cand, n / FA_TRIP, words);
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int wd = 0; wd < GRP_WORDS; wd++) {
+                unsigned all = 0u;
+#pragma unroll
+                for (int k = 0; k < NB; k++) all |= words[k][wd];
+                if (all) atomicOr(&L.wg_bits[wd], all);
+            }
+        }
+        __syncthreads();
+        unsigned chunks[GRP_WORDS];
+#pragma unroll
+        for (int wd = 0; wd < GRP_WORDS; wd++) chunks[wd] = L.wg_bits[wd];
+#pragma clang loop unroll(disable)
+        for (int c = 0; c < n; c++) {
+            // bit 8t + 7 - m of word w = entry 8(4w + t) + m
+            const unsigned word = c < 32 ? chunks[0] : (c < 64 ? chunks[1] : (c < 96 ? chunks[2] : chunks[3]));
+            if (!((word >> (((c & 31) & ~7) + 7 - (c & 7))) & 1u)) continue;
+            const int base = (first + c) * SPH_CHUNK;
+            if (base < nsp) visit(base, min(SPH_CHUNK, nsp - base));
+        }
     }
 }
 
@@ -687,11 +883,10 @@ __device__ __forceinline__ f3 primary_direction(const DevCamera &cam, int px, in
 // ---------------------------------------------------------------------------------------
 #define PRIM_PX 4   // pixels per lane (2x2)
 
-__global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevFrame f, int32_t *pixels)
+template <bool MULTI>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_primary(DevScene s, DevCamera cam, DevFrame f, int32_t *pixels)
 {
-    __shared__ float4 lds[SPH_CHUNK];
-    __shared__ float4 ldg[GRP_LDS_ENTRIES];
-    __shared__ int cand[QUEUE_INTS];
+    __shared__ WalkLds L;
     __shared__ int blk[12];
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -699,11 +894,10 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
     const int tiles_x = (cam.width + 31) >> 5, tiles_y = (rows + 31) >> 5;
     const int ntiles = tiles_x * tiles_y;
     const int nsp = s.ns_padded;
-    const bool single = nsp <= SPH_CHUNK;
     const f3 o = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
     const FilterOrigin fo = filter_origin(s, o);
-    if (single) {
-        stage_chunk(lds, ldg, s.sph_cam, s.grp_cam, 0, nsp);
+    if (!MULTI) {
+        stage_chunk(L, s.sph_cam, s.grp_cam, s.sup_cam, 0, nsp);
         __syncthreads();
     }
     FilterWork fw = {0, 0, 0};
@@ -732,30 +926,35 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, DevCamera cam, DevF
         f4raw rq[4];
 #pragma unroll
         for (int k = 0; k < PRIM_PX; k++) rq[k] = filter_ray(fo, d[k]);
-        for (int base = 0; base < nsp; base += SPH_CHUNK) {
-            const int cnt = min(SPH_CHUNK, nsp - base);
-            if (!single) {
-                __syncthreads();
-                stage_chunk(lds, ldg, s.sph_cam, s.grp_cam, base, cnt);
-                __syncthreads();
-            }
-            // Exact evaluation of a candidate: objects.cs:112-121 literally; among equal
-            // distances the lower host index wins, as the strict `<` of MyApplication.cs:361
-            // decides when the primitives are scanned in host order.
-            walk_chunk<PRIM_PX, false, false>(lds, ldg, cand, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_g, fo.lane,
-                                       fw, pc, [&](auto, const float4 sp, const int orig) {
-                const f3 op = sub3(o, xyz(sp));
-                const float c = dot3(op, op) - sp.w;
+        // Exact evaluation of a candidate: objects.cs:112-121 literally; among equal
+        // distances the lower host index wins, as the strict `<` of MyApplication.cs:361
+        // decides when the primitives are scanned in host order.
+        auto exact = [&](auto, const float4 sp, const int orig) {
+            const f3 op = sub3(o, xyz(sp));
+            const float c = dot3(op, op) - sp.w;
 #pragma unroll
-                for (int k = 0; k < PRIM_PX; k++) {
-                    const float xx = dot3(d[k], op);
-                    float t;
-                    if (sphere_maybe(xx, a[k] * c) && sphere_root(xx, c, a[k], t) && t > RT_EPS &&
-                        (t < best_t[k] || (t == best_t[k] && orig < best_prim[k]))) {
-                        best_t[k] = t;
-                        best_prim[k] = orig;
-                    }
+            for (int k = 0; k < PRIM_PX; k++) {
+                const float xx = dot3(d[k], op);
+                float t;
+                if (sphere_maybe(xx, a[k] * c) && sphere_root(xx, c, a[k], t) && t > RT_EPS &&
+                    (t < best_t[k] || (t == best_t[k] && orig < best_prim[k]))) {
+                    best_t[k] = t;
+                    best_prim[k] = orig;
                 }
+            }
+        };
+        if constexpr (!MULTI) {
+            if (nsp > 0)
+                walk_chunk<PRIM_PX, false, false>(L, nsp, s.sph, s.sph_orig, rq, fo.lane_s, fo.lane_g, fo.lane, fw, pc,
+                                                  exact);
+        } else {
+            for_each_chunk<PRIM_PX, false, false>(L, nsp, s.nchk_padded, s.chk_cam, rq, fo.lane_c, fw,
+                                                  [&](const int base, const int cnt) {
+                __syncthreads();
+                stage_chunk(L, s.sph_cam, s.grp_cam, s.sup_cam, base, cnt);
+                __syncthreads();
+                walk_chunk<PRIM_PX, false, false>(L, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_s, fo.lane_g,
+                                                  fo.lane, fw, pc, exact);
             });
         }
         bool rec_valid[PRIM_PX];
@@ -824,8 +1023,8 @@ struct Rays {
     Closest sec;
 };
 
-template <int LC, bool SEC, bool SPLIT>
-__device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, float4 *ldg, int *cand, const bool single,
+template <int LC, bool SEC, bool SPLIT, bool MULTI>
+__device__ __forceinline__ void traverse(const DevScene &s, WalkLds &L,
                                          const f3 o, Rays<LC, SEC> &r, TestCount &tc, PhaseClock &pc)
 {
     constexpr int NR = LC + (SEC ? 1 : 0);
@@ -843,40 +1042,44 @@ __device__ __forceinline__ void traverse(const DevScene &s, float4 *lds, float4 
     int best_prim = INT_MAX;   // host index of the closest sphere so far
     FilterWork fw = {0, 0, 0};
     const int nsp = s.ns_padded;
-    for (int base = 0; base < nsp; base += SPH_CHUNK) {
-        const int cnt = min(SPH_CHUNK, nsp - base);
-        if (!single) {
-            __syncthreads();
-            stage_chunk(lds, ldg, s.sph_f, s.grp_f, base, cnt);
-            __syncthreads();
+    // Exact evaluation of a candidate (Sphere.Intersect objects.cs:112-121, literally) for ray
+    // k of the record (lights first, then the reflection ray), or for all rays (k = -1).
+    // Closest hit: among equal distances the lower host index wins (MyApplication.cs:361);
+    // shadow rays: the lowest host index among the occluders is the one the reference
+    // meets first (MyApplication.cs:373-378).
+    auto exact = [&](auto kc, const float4 sp, const int orig) {
+        constexpr int k = decltype(kc)::value;
+        const f3 op = sub3(o, xyz(sp));
+        const float c = dot3(op, op) - sp.w;
+        float t;
+        if constexpr (SEC && (k < 0 || k == LC)) {
+            const float x = dot3(r.sec_d, op);
+            if (sphere_maybe(x, r.sec_a * c) && sphere_root(x, c, r.sec_a, t) && t > RT_EPS &&
+                (t < best_t || (t == best_t && orig < best_prim))) {
+                best_t = t;
+                best_prim = orig;
+            }
         }
-        // Exact evaluation of a candidate (Sphere.Intersect objects.cs:112-121, literally) for ray
-        // k of the record (lights first, then the reflection ray), or for all rays (k = -1).
-        // Closest hit: among equal distances the lower host index wins (MyApplication.cs:361);
-        // shadow rays: the lowest host index among the occluders is the one the reference
-        // meets first (MyApplication.cs:373-378).
-        walk_chunk<NR, true, SPLIT>(lds, ldg, cand, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_g, fo.lane, fw,
-                                    pc, [&](auto kc, const float4 sp, const int orig) {
-            constexpr int k = decltype(kc)::value;
-            const f3 op = sub3(o, xyz(sp));
-            const float c = dot3(op, op) - sp.w;
-            float t;
-            if constexpr (SEC && (k < 0 || k == LC)) {
-                const float x = dot3(r.sec_d, op);
-                if (sphere_maybe(x, r.sec_a * c) && sphere_root(x, c, r.sec_a, t) && t > RT_EPS &&
-                    (t < best_t || (t == best_t && orig < best_prim))) {
-                    best_t = t;
-                    best_prim = orig;
-                }
-            }
 #pragma unroll
-            for (int l = 0; l < LC; l++) {
-                if (k >= 0 && l != k) continue;
-                const float x = dot3(r.sh_d[l], op);
-                if (sphere_maybe(x, r.sh_a[l] * c) && sphere_root(x, c, r.sh_a[l], t) && t > RT_EPS &&
-                    t < r.sh_dist[l])
-                    r.sh_first[l] = min(r.sh_first[l], orig);
-            }
+        for (int l = 0; l < LC; l++) {
+            if (k >= 0 && l != k) continue;
+            const float x = dot3(r.sh_d[l], op);
+            if (sphere_maybe(x, r.sh_a[l] * c) && sphere_root(x, c, r.sh_a[l], t) && t > RT_EPS &&
+                t < r.sh_dist[l])
+                r.sh_first[l] = min(r.sh_first[l], orig);
+        }
+    };
+    if constexpr (!MULTI) {   // the scene's spheres are one chunk, staged once per workgroup
+        if (nsp > 0)
+            walk_chunk<NR, true, SPLIT>(L, nsp, s.sph, s.sph_orig, rq, fo.lane_s, fo.lane_g, fo.lane, fw, pc, exact);
+    } else {
+        for_each_chunk<NR, true, SPLIT>(L, nsp, s.nchk_padded, s.chk_f, rq, fo.lane_c, fw,
+                                        [&](const int base, const int cnt) {
+            __syncthreads();
+            stage_chunk(L, s.sph_f, s.grp_f, s.sup_f, base, cnt);
+            __syncthreads();
+            walk_chunk<NR, true, SPLIT>(L, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_s, fo.lane_g, fo.lane,
+                                        fw, pc, exact);
         });
     }
     tc.exact += fw.candidates;
@@ -931,8 +1134,8 @@ __device__ __forceinline__ f3 record_normal(const DevScene &s, int prim, int typ
 
 
 // One chunk of LC lights (plus the reflection ray when SEC) for one record.
-template <int LC, bool SEC, bool SPLIT>
-__device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, float4 *ldg, int *cand, const bool single, const f3 hit,
+template <int LC, bool SEC, bool SPLIT, bool MULTI>
+__device__ __forceinline__ void trace_chunk(const DevScene &s, WalkLds &L, const f3 hit,
                                             const f3 view, const f3 normal, int l0, uint32_t &mask_word,
                                             Closest &sec_out, f3 &sec_dir, TestCount &tc, PhaseClock &pc)
 {
@@ -953,7 +1156,7 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, floa
         r.sec.t = RT_FLT_MAX;
         r.sec.prim = INT_MAX;
     }
-    traverse<LC, SEC, SPLIT>(s, lds, ldg, cand, single, hit, r, tc, pc);
+    traverse<LC, SEC, SPLIT, MULTI>(s, L, hit, r, tc, pc);
     PHASE_MARK(pc, 6)
 #pragma unroll
     for (int l = 0; l < LC; l++) {
@@ -975,14 +1178,13 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, float4 *lds, floa
     }
 }
 
-// One tile = 256 consecutive records of one queue of one level, one record per lane.
-// SEC: the records of the level that need a reflection trace (queue "A") or the others
-// ("B").  LCMAX: lights handled per scene walk (2 or 4); with few lights the 2-light
-// instance is used, which needs far fewer registers.  n = records in the queue.
-// Every thread of the workgroup must call it (barriers inside).
-template <bool SEC, int LCMAX>
-__device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f, float4 *lds, float4 *ldg, int *cand, int *blk,
-                                           const bool single, const int level, const int tile, const int n,
+// One walk of one tile = 256 consecutive records of one queue of one level, one record per
+// lane.  SEC: the records of the level that need a reflection trace (queue "A") or the others
+// ("B"); walk: which of the records' walks (walks_of).  LCMAX = walk_lcmax(lights of the scene).
+// n = records in the queue.  Every thread of the workgroup must call it (barriers inside).
+template <bool SEC, int LCMAX, bool MULTI>
+__device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f, WalkLds &L, int *blk,
+                                           const int level, const int tile, const int n, const int walk,
                                            TestCount &tc, PhaseClock &pc)
 {
     PHASE_MARK(pc, 0)
@@ -1000,47 +1202,37 @@ __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f,
     f3 sec_dir = mk3(0.0f, 0.0f, 0.0f);
     TestCount ltc = {0, 0, 0, 0, 0, 0};
     uint32_t word = 0;
-    int l0 = 0;
-    bool first = true;
     const int nl = s.nl;
-    // Lights in chunks of up to 2 (LCMAX 2: scenes with fewer than four lights, combined filter
-    // loops, at most three rays per walk) or up to 4 (LCMAX 4: split loops, at most four rays per
-    // walk, so the chunk that carries the reflection ray has one light fewer).
-#define RT_CHUNK(LC_, SEC_) trace_chunk<LC_, SEC_, (LCMAX >= 4)>(s, lds, ldg, cand, single, hit, view, normal, l0, word, sec, sec_dir, ltc, pc)
-    while (l0 < nl || (SEC && first)) {
-        const int rem = min(nl - l0, 32 - (l0 & 31));   // a walk's lights share one mask word
-        const bool with_sec = SEC && first;
-        bool done = false;
-        if constexpr (LCMAX >= 4) {
-            if (!with_sec && rem >= 4) {
-                RT_CHUNK(4, false);
-                l0 += 4;
-                done = true;
-            } else if (rem >= 3) {
-                if (with_sec) RT_CHUNK(3, true);
-                else RT_CHUNK(3, false);
-                l0 += 3;
-                done = true;
-            }
+    const bool with_sec = SEC && walk == 0;
+    int l0, count;
+    walk_lights(SEC, walk, nl, l0, count);
+#define RT_WALK(LC_, SEC_) trace_chunk<LC_, SEC_, (LCMAX >= 4), MULTI>(s, L, hit, view, normal, l0, word, sec, sec_dir, ltc, pc)
+    bool done = false;
+    if constexpr (LCMAX >= 4) {
+        if (count == 4) {   // never with the reflection ray: a walk has at most four rays
+            RT_WALK(4, false);
+            done = true;
+        } else if (count == 3) {
+            if (SEC && with_sec) RT_WALK(3, true);
+            else RT_WALK(3, false);
+            done = true;
         }
-        if (done) {
-        } else if (rem >= 2) {
-            if (with_sec) RT_CHUNK(2, true);
-            else RT_CHUNK(2, false);
-            l0 += 2;
-        } else if (rem == 1) {
-            if (with_sec) RT_CHUNK(1, true);
-            else RT_CHUNK(1, false);
-            l0 += 1;
-        } else {
-            RT_CHUNK(0, true);
-        }
-#undef RT_CHUNK
-        first = false;
-        if (l0 > 0 && ((l0 & 31) == 0 || l0 >= nl)) {
-            if (active) f.mask[(size_t)((l0 - 1) >> 5) * (size_t)f.slots + slot] = word;
-            word = 0;
-        }
+    }
+    if (done) {
+    } else if (count == 2) {
+        if (SEC && with_sec) RT_WALK(2, true);
+        else RT_WALK(2, false);
+    } else if (count == 1) {
+        if (SEC && with_sec) RT_WALK(1, true);
+        else RT_WALK(1, false);
+    } else if (SEC && with_sec) {
+        RT_WALK(0, true);
+    }
+#undef RT_WALK
+    if (active && count > 0) {
+        uint32_t *mw = &f.mask[(size_t)(l0 >> 5) * (size_t)f.slots + slot];
+        if (walks_of(SEC, nl) == 1) *mw = word;   // the only writer of the record's (single) word
+        else if (word) atomicOr(mw, word);         // zeroed when the record was written
     }
     if (active) {
         tc.sph += ltc.sph;
@@ -1050,7 +1242,7 @@ __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f,
     }
     tc.filt_terms += ltc.filt_terms;   // inactive lanes run the loops too
     tc.filt_rays += ltc.filt_rays;
-    if (SEC) {
+    if (SEC && with_sec) {   // workgroup-uniform
         const bool child = active && sec.prim != INT_MAX;
         const f3 hit2 = add3(hit, scale3(sec_dir, sec.t));   // objects.cs:123,166,263
         if (active) f.refl[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1075,26 +1267,24 @@ __device__ __forceinline__ void flush_test_counts(const DevFrame &f, unsigned lo
 
 // One queue of one level per launch (the form a kernel trace can attribute time to; the
 // frame pipeline normally uses k_trace_levels below).
-template <bool SEC, int LCMAX>
+template <bool SEC, int LCMAX, bool MULTI>
 __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level)
 {
-    __shared__ float4 lds[SPH_CHUNK];
-    __shared__ float4 ldg[GRP_LDS_ENTRIES];
-    __shared__ int cand[QUEUE_INTS];
+    __shared__ WalkLds L;
     __shared__ int blk[12];
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int n = SEC ? f.cnt[2 * level] : f.cnt[2 * level + 1];
     const int ntiles = (n + 255) >> 8;
-    const bool single = s.ns_padded <= SPH_CHUNK;
-    if (single && (int)blockIdx.x < ntiles) {
-        stage_chunk(lds, ldg, s.sph_f, s.grp_f, 0, s.ns_padded);
+    if (!MULTI && (int)blockIdx.x < ntiles) {
+        stage_chunk(L, s.sph_f, s.grp_f, s.sup_f, 0, s.ns_padded);
         __syncthreads();
     }
     TestCount tc = {0, 0, 0, 0, 0, 0};
     PhaseClock pc = {};
     // Workgroup-uniform trip count: the sphere chunks are staged between barriers.
+    const int walks = walks_of(SEC, s.nl);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
-        trace_tile<SEC, LCMAX>(s, f, lds, ldg, cand, blk, single, level, tile, n, tc, pc);
+        for (int walk = 0; walk < walks; walk++) trace_tile<SEC, LCMAX, MULTI>(s, f, L, blk, level, tile, n, walk, tc, pc);
     flush_test_counts(f, cnt_sh, tc);
 }
 
@@ -1145,20 +1335,20 @@ struct Taker {
     unsigned spins;
 };
 
-template <int LCMAX>
+template <int LCMAX, bool MULTI>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 k_trace_levels(DevScene s, DevFrame f)
 {
-    __shared__ float4 lds[SPH_CHUNK];
-    __shared__ float4 ldg[GRP_LDS_ENTRIES];
-    __shared__ int cand[QUEUE_INTS];
+    __shared__ WalkLds L;
     __shared__ int blk[12];
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
-    __shared__ int job[4];
-    __shared__ int lv_a[RT_DEV_MAX_LEVELS], lv_b[RT_DEV_MAX_LEVELS];   // record counts of the seen levels (thread 0)
+    __shared__ int job[5];
+    // Record counts of the seen levels and what is left to claim of their plain jobs (thread 0).
+    __shared__ int lv_a[RT_DEV_MAX_LEVELS], lv_b[RT_DEV_MAX_LEVELS], lv_jobs[RT_DEV_MAX_LEVELS];
     DevSched *const sc = f.sched;
     const int D = f.max_depth;
-    const bool single = s.ns_padded <= SPH_CHUNK;
+    // Plain jobs of a level: every walk of its B tiles and the walks after the first of its A tiles.
+    const int walks_a = walks_of(true, s.nl), walks_b = walks_of(false, s.nl);
     bool staged = false;
     TestCount tc = {0, 0, 0, 0, 0, 0};
     PhaseClock pc = {};
@@ -1171,41 +1361,53 @@ k_trace_levels(DevScene s, DevFrame f)
 #endif
     for (;;) {
         if (threadIdx.x == 0) {
-            int kind = SCHED_JOB_EXIT, lvl = 0, tile = 0, n = 0;
+            int kind = SCHED_JOB_EXIT, lvl = 0, tile = 0, n = 0, walk = 0;
             for (;;) {
                 // What this workgroup believes is claimable, A tiles of the newest level first.
                 int *ctr = nullptr;
-                int cand_kind = SCHED_JOB_EXIT, cand_lvl = 0, cand_n = 0;
+                int cand_kind = SCHED_JOB_EXIT, cand_lvl = 0, cand_jobs = 0;
                 if (tk.a_left) {
                     ctr = &sc->next_a[tk.seen_open];
-                    cand_kind = SCHED_JOB_A, cand_lvl = tk.seen_open, cand_n = lv_a[tk.seen_open];
+                    cand_kind = SCHED_JOB_A, cand_lvl = tk.seen_open, cand_jobs = (lv_a[tk.seen_open] + 255) >> 8;
                 } else {
-                    while (tk.b_level <= tk.seen_open && lv_b[tk.b_level] < 0) tk.b_level++;
+                    while (tk.b_level <= tk.seen_open && lv_jobs[tk.b_level] < 0) tk.b_level++;
                     if (tk.b_level <= tk.seen_open) {
                         ctr = &sc->next_b[tk.b_level];
-                        cand_kind = SCHED_JOB_B, cand_lvl = tk.b_level, cand_n = lv_b[tk.b_level];
+                        cand_kind = SCHED_JOB_B, cand_lvl = tk.b_level, cand_jobs = lv_jobs[tk.b_level];
                     }
                 }
                 // One round trip: the level check and the claim travel together.
                 const int open = sched_load(&sc->open_level);
                 const int t = ctr ? atomicAdd(ctr, 1) : 0;
-                const bool claimed = ctr && t < ((cand_n + 255) >> 8);
+                const bool claimed = ctr && t < cand_jobs;
                 if (ctr && !claimed) {   // that queue is exhausted
                     if (cand_kind == SCHED_JOB_A) tk.a_left = false;
-                    else lv_b[cand_lvl] = -1;
+                    else lv_jobs[cand_lvl] = -1;
                 }
                 const bool opened = open > tk.seen_open;
                 if (opened) {
                     for (int k = tk.seen_open + 1; k <= open; k++) {
                         lv_a[k] = k < D ? sched_load(&f.cnt[2 * k]) : 0;
-                        const int nb = sched_load(&f.cnt[2 * k + 1]);
-                        lv_b[k] = nb > 0 ? nb : -1;   // -1: nothing (left) to claim
+                        lv_b[k] = sched_load(&f.cnt[2 * k + 1]);
+                        const int jobs = ((lv_b[k] + 255) >> 8) * walks_b + ((lv_a[k] + 255) >> 8) * (walks_a - 1);
+                        lv_jobs[k] = jobs > 0 ? jobs : -1;   // -1: nothing (left) to claim
                     }
                     tk.seen_open = open;
                     tk.a_left = lv_a[open] > 0;
                 }
                 if (claimed) {
-                    kind = cand_kind, lvl = cand_lvl, tile = t, n = cand_n;
+                    kind = cand_kind, lvl = cand_lvl;
+                    if (kind == SCHED_JOB_A) {
+                        tile = t, n = lv_a[lvl], walk = 0;
+                    } else {
+                        const int plain = ((lv_b[lvl] + 255) >> 8) * walks_b;
+                        if (t < plain) {
+                            tile = t / walks_b, walk = t % walks_b, n = lv_b[lvl];
+                        } else {   // a later walk of a reflecting tile: no successors either
+                            kind = SCHED_JOB_A;
+                            tile = (t - plain) / (walks_a - 1), walk = 1 + (t - plain) % (walks_a - 1), n = lv_a[lvl];
+                        }
+                    }
                     break;
                 }
                 if (ctr || opened) continue;
@@ -1222,25 +1424,23 @@ k_trace_levels(DevScene s, DevFrame f)
             job[1] = lvl;
             job[2] = tile;
             job[3] = n;
+            job[4] = walk;
         }
         __syncthreads();
-        const int kind = job[0], lvl = job[1], tile = job[2], n = job[3];
+        const int kind = job[0], lvl = job[1], tile = job[2], n = job[3], walk = job[4];
         if (kind == SCHED_JOB_EXIT) break;
-        if (single && !staged) {
-            stage_chunk(lds, ldg, s.sph_f, s.grp_f, 0, s.ns_padded);
+        if (!MULTI && !staged) {
+            stage_chunk(L, s.sph_f, s.grp_f, s.sup_f, 0, s.ns_padded);
             staged = true;
         }
         __syncthreads();   // job[] read by all, spheres staged
-        if (kind == SCHED_JOB_A) {
+        if (kind == SCHED_JOB_A && walk == 0) {
             __builtin_amdgcn_s_setprio(3);   // the chain of levels is the launch's critical path
-            trace_tile<true, LCMAX>(s, f, lds, ldg, cand, blk, single, lvl, tile, n, tc, pc);
+            trace_tile<true, LCMAX, MULTI>(s, f, L, blk, lvl, tile, n, 0, tc, pc);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's record stores have reached memory
             __builtin_amdgcn_s_setprio(0);
             __syncthreads();
             if (threadIdx.x == 0) {
-#ifdef RT_SCHED_RELEASE_FENCE
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
                 const int tiles_a = (n + 255) >> 8;
                 if (atomicAdd(&sc->done_a[lvl], 1) + 1 == tiles_a) {
 #ifdef RT_SCHED_TIMELINE
@@ -1249,8 +1449,10 @@ k_trace_levels(DevScene s, DevFrame f)
                     __hip_atomic_store(&sc->open_level, lvl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+        } else if (kind == SCHED_JOB_A) {
+            trace_tile<true, LCMAX, MULTI>(s, f, L, blk, lvl, tile, n, walk, tc, pc);
         } else {
-            trace_tile<false, LCMAX>(s, f, lds, ldg, cand, blk, single, lvl, tile, n, tc, pc);
+            trace_tile<false, LCMAX, MULTI>(s, f, L, blk, lvl, tile, n, walk, tc, pc);
         }
     }
 #ifdef RT_SCHED_TIMELINE
@@ -1399,42 +1601,56 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
 // ---------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------
-void rtk_setup_camera(const DevScene &s, const DevCamera &cam, float4 *sph_cam, float4 *grp_cam,
-                      hipStream_t stream)
+void rtk_setup_camera(const DevScene &s, const DevCamera &cam, hipStream_t stream)
 {
     if (s.ns_padded <= 0) return;
-    hipLaunchKernelGGL(k_setup_camera, dim3((s.ns_padded + 255) / 256), dim3(256), 0, stream, s, cam, sph_cam,
-                       grp_cam);
+    hipLaunchKernelGGL(k_setup_camera, dim3((s.ns_padded + 255) / 256), dim3(256), 0, stream, s, cam);
 }
+
+// Scenes whose spheres fit one LDS chunk use the kernels that stage it once per workgroup.
+static bool multi_chunk(const DevScene &s) { return s.ns_padded > SPH_CHUNK; }
 
 void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels, int grid_blocks,
                  hipStream_t stream)
 {
     const int rows = cam.row_end - cam.row_begin;
     const int ntiles = ((cam.width + 31) / 32) * ((rows + 31) / 32);  // 32x32 pixels per workgroup trip
-    hipLaunchKernelGGL(k_primary, dim3(ntiles < grid_blocks ? ntiles : grid_blocks), dim3(256), 0, stream, s, cam, f,
-                       pixels);
+    const dim3 g(ntiles < grid_blocks ? ntiles : grid_blocks), b(256);
+    if (multi_chunk(s)) hipLaunchKernelGGL(k_primary<true>, g, b, 0, stream, s, cam, f, pixels);
+    else hipLaunchKernelGGL(k_primary<false>, g, b, 0, stream, s, cam, f, pixels);
+}
+
+template <bool MULTI>
+static void launch_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting, dim3 g, dim3 b,
+                         hipStream_t stream)
+{
+    if (s.nl >= 4) {
+        if (reflecting) hipLaunchKernelGGL((k_trace<true, 4, MULTI>), g, b, 0, stream, s, f, level);
+        else hipLaunchKernelGGL((k_trace<false, 4, MULTI>), g, b, 0, stream, s, f, level);
+    } else {
+        if (reflecting) hipLaunchKernelGGL((k_trace<true, 2, MULTI>), g, b, 0, stream, s, f, level);
+        else hipLaunchKernelGGL((k_trace<false, 2, MULTI>), g, b, 0, stream, s, f, level);
+    }
 }
 
 void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting, int grid_blocks,
                hipStream_t stream)
 {
-    const dim3 g(grid_blocks), b(256);
-    if (s.nl >= 4) {
-        if (reflecting) hipLaunchKernelGGL((k_trace<true, 4>), g, b, 0, stream, s, f, level);
-        else hipLaunchKernelGGL((k_trace<false, 4>), g, b, 0, stream, s, f, level);
-    } else {
-        if (reflecting) hipLaunchKernelGGL((k_trace<true, 2>), g, b, 0, stream, s, f, level);
-        else hipLaunchKernelGGL((k_trace<false, 2>), g, b, 0, stream, s, f, level);
-    }
+    if (multi_chunk(s)) launch_trace<true>(s, f, level, reflecting, dim3(grid_blocks), dim3(256), stream);
+    else launch_trace<false>(s, f, level, reflecting, dim3(grid_blocks), dim3(256), stream);
 }
 
-int rtk_trace_levels_resident_blocks(int nl, int num_cus)
+typedef void (*trace_levels_kernel)(DevScene, DevFrame);
+static trace_levels_kernel trace_levels_for(const DevScene &s)
+{
+    if (multi_chunk(s)) return s.nl >= 4 ? k_trace_levels<4, true> : k_trace_levels<2, true>;
+    return s.nl >= 4 ? k_trace_levels<4, false> : k_trace_levels<2, false>;
+}
+
+int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus)
 {
     int per_cu = 0;
-    const hipError_t e = nl >= 4
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_levels<4>, 256, 0)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_levels<2>, 256, 0);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_levels_for(s), 256, 0);
     if (e != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 1;
@@ -1444,9 +1660,7 @@ int rtk_trace_levels_resident_blocks(int nl, int num_cus)
 
 void rtk_trace_levels(const DevScene &s, const DevFrame &f, int grid_blocks, hipStream_t stream)
 {
-    const dim3 g(grid_blocks), b(256);
-    if (s.nl >= 4) hipLaunchKernelGGL(k_trace_levels<4>, g, b, 0, stream, s, f);
-    else hipLaunchKernelGGL(k_trace_levels<2>, g, b, 0, stream, s, f);
+    hipLaunchKernelGGL(trace_levels_for(s), dim3(grid_blocks), dim3(256), 0, stream, s, f);
 }
 
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,

@@ -43,6 +43,9 @@ bit 7-m, 1 = cannot hit).  Two kinds of loop are generated:
       The verdict is "the ray's half-line meets the ball":
           v1 = fma(x', x', -c'');  reject = (sign(v1) | sign(x')) & sign(c'')
       Behind the last trip there must be 4 more entries (the loop reads one batch ahead).
+  GSEL loops   run the trips of the ball array that a wave-uniform bitmap names (same bitmap
+      format and prefetching as the SEL loops) and store each trip's mask to the queue slot of
+      that trip like a GROUP loop; the caller fills the slots of the other trips.
   SEL loops    run the sphere trips named by a wave-uniform bitmap of two 64-bit halves (bit b
       of the low half = trip trip0 + (b ^ 7); the high half follows 64 trips later), lowest
       bit first; the first batch of the next selected trip is
@@ -63,6 +66,7 @@ MASK = 25
 # Per-ray reject masks of the split GROUP loops (ray k's verdict register sits in bank 1, 0, 3, 1
 # for k = 0..3 and must not share a bank with the mask it is shifted into).
 RAYMASK = (86, 87, 88, 90)
+QTMP = 89   # queue address of the trip a GSEL loop stores
 SET = (lambda u: 26 + 4 * u, lambda u: 42 + 4 * u)
 QUAD = lambda i: 58 + 4 * i
 SA = lambda u: QUAD(u)
@@ -300,6 +304,45 @@ def sel_loop(K, trace):
     return L
 
 
+def gsel_loop(K, trace, split=False):
+    """GSEL loop: the trips of the ball array named by the bitmap (as in the SEL loops), each
+    trip's mask(s) stored to the lane's queue slot of that trip (as in the GROUP loops);
+    s95 = current trip, s93 = next or -1."""
+    L = []
+    L.append("s_waitcnt lgkmcnt(0)")          # the in-order counting below starts from zero
+    next_trip(L, "s95", "R0")
+    sel_loads(L, 0, 0)
+    L.append(".LFA_LOOP%=:")
+    sel_loads(L, 1, 16 * NB)
+    L.append(f"s_waitcnt lgkmcnt({NB})")      # in order: the first batch (and the last store) are done
+    phase(L, K, trace, 0, 0, ball=True, split=split)
+    L.append("s_mov_b32 s93, -1")
+    L.append("s_or_b64 s[88:89], %[wlo], %[whi]")
+    L.append("s_cmp_eq_u64 s[88:89], 0")
+    L.append("s_cbranch_scc1 .LFA_LAST%=")
+    next_trip(L, "s93", "R1")
+    L.append("s_waitcnt lgkmcnt(0)")
+    sel_loads(L, 0, 0)                         # the next trip's first batch flies during phase 1
+    L.append("s_branch .LFA_PH1%=")
+    L.append(".LFA_LAST%=:")
+    L.append("s_waitcnt lgkmcnt(0)")
+    L.append(".LFA_PH1%=:")
+    phase(L, K, trace, 1, 1, ball=True, split=split)
+    if split:
+        for k in range(1, K):
+            src = RAYMASK[0] if k == 1 else MASK
+            check3(RAYMASK[k], src)
+            L.append(f"v_lshl_or_b32 v{MASK}, v{RAYMASK[k]}, {8 * k}, v{src}")
+    L.append(f"s_lshl_b32 s97, s95, {QSTRIDE.bit_length() - 1}")
+    L.append(f"v_add_u32 v{QTMP}, s97, %[qaddr]")
+    L.append(f"ds_write_b32 v{QTMP}, v{MASK}")
+    L.append("s_mov_b32 s95, s93")
+    L.append("s_cmp_lt_i32 s93, 0")
+    L.append("s_cbranch_scc0 .LFA_LOOP%=")
+    L.append("s_waitcnt lgkmcnt(0)")          # nothing of ours may still be in flight outside
+    return L
+
+
 def written_registers(lines):
     """Every VGPR an instruction of the loop writes (its first operand, or a ds_read's tuple)."""
     regs = set()
@@ -317,12 +360,12 @@ def written_registers(lines):
 
 
 def emit(name, K, trace, kind, split=False):
-    lines = group_loop(K, trace, split) if kind == "group" else sel_loop(K, trace)
+    lines = {"group": group_loop, "gsel": gsel_loop}[kind](K, trace, split) if kind != "sel" else sel_loop(K, trace)
     probe = []
-    phase(probe, K, trace, 0, 0, ball=(kind == "group"), split=split)
-    phase(probe, K, trace, 1, 1, ball=(kind == "group"), split=split)
+    phase(probe, K, trace, 0, 0, ball=(kind != "sel"), split=split)
+    phase(probe, K, trace, 1, 1, ball=(kind != "sel"), split=split)
     valu = sum(1 for l in probe if l.startswith("v_")) + (2 if kind == "group" else 3) + (K - 1 if split else 0)
-    what = "ball" if kind == "group" else "sphere"
+    what = "sphere" if kind == "sel" else "ball"
     out = [f"// {name}: {kind} loop, {'shared origin' if trace else 'precomputed -c'}, {K} ray(s) per lane, "
            f"~{valu} VALU instructions per trip of {2 * NB} {what}s when nothing is queued"]
     out.append(f"#define {name}_VALU {valu}")
@@ -358,6 +401,8 @@ def main():
     out.append("")
     out += emit("FA_PSEL4", 4, False, "sel")
     out.append("")
+    out += emit("FA_PGSEL4", 4, False, "gsel")
+    out.append("")
     # Trace loops, two families.  Combined (scenes with few lights, K <= 3): the K rays of a
     # record share one reject mask per ball and per sphere.  Split (K <= 4): the balls are
     # tested for all K rays at once (they share the per-origin term) with one reject mask per
@@ -368,8 +413,12 @@ def main():
         out.append("")
         out += emit(f"FA_SEL{K}", K, True, "sel")
         out.append("")
+        out += emit(f"FA_GSEL{K}", K, True, "gsel")
+        out.append("")
     for K in range(2, 5):
         out += emit(f"FA_GROUPS{K}", K, True, "group", split=True)
+        out.append("")
+        out += emit(f"FA_GSELS{K}", K, True, "gsel", split=True)
         out.append("")
     with open(path, "w") as f:
         f.write("\n".join(out))
