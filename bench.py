@@ -2,10 +2,12 @@
 """bench.py — Mrays/s of the render loop on the 1k-sphere scene at 3840x2160, 4 bounces.
 
 One process per GPU (`python bench.py` for one GPU; the driver launches N ranks through
-torch.distributed.run).  A step is one frame: every rank renders its block of rows of the
-SAME 3840x2160 frame through rt_render_rows_device (scene and scratch resident in HBM),
-then the blocks are gathered on rank 0 with one RCCL collective (torch.distributed
-backend "nccl").  Total work is fixed as N grows: strong scaling.
+torch.distributed.run).  A step is one frame: every rank renders its rows of the SAME
+3840x2160 frame (every N-th band of 16 rows: rt_render_bands_device; scene and scratch
+resident in HBM), then the blocks are gathered on rank 0 with one RCCL collective
+(torch.distributed backend "nccl") and put back in row order.  Total work is fixed as N
+grows: strong scaling.  The timed frames run without the library's counters; the ray counts
+and per-kernel HIP-event times come from one more frame rendered afterwards with them on.
 
 Printed by rank 0: one JSON line with
   value        whole-job Mrays/s = (primary + shadow + used reflection rays per frame,
@@ -35,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from raytracer_amd import Camera, RenderContext, scene_1k  # noqa: E402
-from raytracer_amd.distributed import FrameGatherer, row_block  # noqa: E402
+from raytracer_amd.distributed import FrameGatherer, render_block  # noqa: E402
 
 WIDTH, HEIGHT, MAX_DEPTH = 3840, 2160, 4
 PEAK_FP32_TFLOPS = 157.3
@@ -87,14 +89,10 @@ def main() -> None:
     flat = scene_1k().flatten()
     ctx = RenderContext([local_rank])
     ctx.set_scene(flat)
-    ctx.set_profiling(True)
     gatherer = FrameGatherer(WIDTH, HEIGHT, rank, world, torch.device("cuda", local_rank))
-    y0, y1 = row_block(HEIGHT, rank, world)
-    stream = torch.cuda.current_stream()
 
     def step() -> None:
-        ctx.render_rows_device(cam, WIDTH, HEIGHT, y0, y1, MAX_DEPTH, gatherer.block.data_ptr(),
-                               stream.cuda_stream)
+        render_block(ctx, cam, WIDTH, HEIGHT, MAX_DEPTH, gatherer)
         gatherer.gather()
 
     def fence() -> None:
@@ -112,7 +110,10 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
 
-    st = ctx.stats()  # counters and HIP-event times of this rank's last timed frame
+    # One more frame with the device-side counters and event timing on (they cost ~2 %).
+    ctx.set_profiling(True)
+    render_block(ctx, cam, WIDTH, HEIGHT, MAX_DEPTH, gatherer)
+    st = ctx.stats()  # synchronises; counters and HIP-event times of this rank's frame
     keys = ("rays_primary", "rays_shadow", "rays_secondary", "shaded_hits", "sphere_tests",
             "plane_tests", "triangle_tests", "filter_ray_tests", "filter_origin_terms", "exact_candidates",
             "primary_filter_ray_tests", "primary_exact_candidates")
@@ -162,7 +163,8 @@ def main() -> None:
                             "3840x2160, 4 mirror bounces",
                 "width": WIDTH, "height": HEIGHT, "max_depth": MAX_DEPTH,
                 "spheres": ns, "planes": npl, "lights": flat.num_lights,
-                "partition": f"{world} contiguous row block(s), RCCL gather to rank 0",
+                "partition": ("whole frame on one GPU" if world == 1 else
+                              f"every {world}th band of 16 rows per rank, RCCL gather to rank 0"),
                 "rays_per_frame": int(rays),
                 "exact_candidates_rank0": int(st["exact_candidates"]),
             },

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RT_API_VERSION 2
+#define RT_API_VERSION 3
 
 /* Primitive type codes — the reference's own flatten uses exactly these
  * (MyApplication.cs:161,166,173). */
@@ -200,7 +200,8 @@ int rt_render(rt_ctx *ctx, const rt_camera *camera, int width, int height,
  * first device into device memory: dev_pixels_out points to (row_end-row_begin) *
  * width int32 on that device; element (y - row_begin) * width + x is pixel (x, y)
  * of the full frame.  The work is enqueued on hip_stream (a hipStream_t; NULL =
- * the default stream) and the call returns without synchronising; per-frame
+ * a non-blocking stream the context owns, which nothing else is ordered against: pass the
+ * stream the consumer of the pixels runs on) and the call returns without synchronising; per-frame
  * scratch is owned by the context, so calls on one context must not overlap.
  * This is the per-rank entry of the one-process-per-GPU row partition: rank r of
  * G renders its block and the framebuffer blocks are gathered with one
@@ -210,6 +211,26 @@ int rt_render(rt_ctx *ctx, const rt_camera *camera, int width, int height,
 int rt_render_rows_device(rt_ctx *ctx, const rt_camera *camera, int width, int height,
                           int row_begin, int row_end, int max_depth,
                           int32_t *dev_pixels_out, void *hip_stream);
+
+/*
+ * The same for an interleaved partition of the frame: the frame is cut into bands of band_rows
+ * consecutive rows (band b = rows [b * band_rows, (b + 1) * band_rows), the last one shorter)
+ * and this call renders the bands b = part, part + parts, part + 2 * parts, ...  The bands are
+ * written one after the other: dev_pixels_out points to rt_band_rows(height, band_rows, part,
+ * parts) * width int32 on the context's first device.  With parts ranks each taking one part
+ * every rank gets the same mix of cheap and expensive image regions (rows cost very different
+ * amounts: mirrors, the reflecting ceiling), which contiguous blocks do not give; the host
+ * interleaves the gathered blocks back.  parts = 1 renders the whole frame.
+ * No counterpart in the reference (its thread pool balances rows dynamically,
+ * MyApplication.cs:408); per pixel the semantics of rt_render (MyApplication.cs:410-424).
+ */
+int rt_render_bands_device(rt_ctx *ctx, const rt_camera *camera, int width, int height,
+                           int band_rows, int part, int parts, int max_depth,
+                           int32_t *dev_pixels_out, void *hip_stream);
+
+/* Rows of a height-row frame that fall to `part` of `parts` with bands of band_rows rows, or
+ * RT_ERR_INVALID_ARG. */
+int rt_band_rows(int height, int band_rows, int part, int parts);
 
 /* Counters and timings of the last render call.  Synchronises the context's
  * devices (needed to read the device-side counters). */

@@ -106,6 +106,12 @@ EXPORTS = {
         [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
          C.c_void_p, C.c_void_p],
     ),
+    "rt_render_bands_device": (
+        C.c_int,
+        [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+         C.c_void_p, C.c_void_p],
+    ),
+    "rt_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(rt_stats)]),
     "rt_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
 }

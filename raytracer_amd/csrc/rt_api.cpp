@@ -19,6 +19,9 @@
 
 namespace {
 
+// Below this many level-0 tiles per resident workgroup a frame is bound by its chain of levels.
+constexpr int RT_CHAIN_BOUND_TILES_PER_WORKGROUP = 8;
+
 thread_local std::string g_create_error;
 
 struct DeviceState {
@@ -401,7 +404,24 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
 }
 
 // GetRayDirection's per-frame part, MyApplication.cs:431-448.
-DevCamera make_camera(const rt_camera *cam, int w, int h, int row_begin, int row_end)
+// The rows a render call covers (DevCamera): `rows` rows starting at row_begin, or every
+// parts-th band of `band` rows of the whole frame.
+struct RowSet {
+    int row_begin, rows, band, parts, part;
+};
+
+RowSet contiguous_rows(int y0, int y1) { return RowSet{y0, y1 - y0, 16, 1, 0}; }
+
+// Rows of a height-row frame in the bands b = part, part + parts, ... of band_rows rows each.
+int rows_of_part(int height, int band_rows, int part, int parts)
+{
+    const int bands = (height + band_rows - 1) / band_rows;
+    long long rows = 0;
+    for (int b = part; b < bands; b += parts) rows += std::min(band_rows, height - b * band_rows);
+    return (int)rows;
+}
+
+DevCamera make_camera(const rt_camera *cam, int w, int h, const RowSet &rs)
 {
     DevCamera c{};
     const float deg2rad = 3.14159274f / 180.0f;  // MathHelper.DegreesToRadians: MathF.PI / 180f
@@ -426,8 +446,11 @@ DevCamera make_camera(const rt_camera *cam, int w, int h, int row_begin, int row
     }
     c.width = w;
     c.height = h;
-    c.row_begin = row_begin;
-    c.row_end = row_end;
+    c.row_begin = rs.row_begin;
+    c.rows = rs.rows;
+    c.band = rs.band;
+    c.parts = rs.parts;
+    c.part = rs.part;
     return c;
 }
 
@@ -473,6 +496,7 @@ int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
     d.frame.slots = (int)slots;
     d.frame.max_depth = max_depth;
     d.frame.mask_words = words;
+    d.frame.first_lights = nl >= 4 ? 3 : 2;
     return RT_OK;
 }
 
@@ -517,11 +541,11 @@ int check_schedule(rt_ctx *ctx, DeviceState &d)
     return RT_OK;
 }
 
-// Enqueue the whole frame pipeline for rows [y0, y1) on device state d.
-int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h, int y0, int y1,
+// Enqueue the whole frame pipeline for the rows of rs on device state d.
+int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h, const RowSet &rs,
                  int max_depth, int32_t *dev_pixels, hipStream_t stream)
 {
-    const long long P64 = (long long)(y1 - y0) * (long long)w;
+    const long long P64 = (long long)rs.rows * (long long)w;
     if (P64 > INT32_MAX) return fail(ctx, RT_ERR_LIMIT, "row block of %lld pixels exceeds 2^31-1", P64);
     const int P = (int)P64;
     d.last_P = P;
@@ -530,12 +554,22 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     HIP_TRY(ctx, hipSetDevice(d.device));
     int rc = ensure_frame(ctx, d, P, max_depth, d.scene.nl);
     if (rc != RT_OK) return rc;
-    const DevCamera dc = make_camera(cam, w, h, y0, y1);
+    const DevCamera dc = make_camera(cam, w, h, rs);
+    const int tiles0 = (P + 255) / 256;
+    if (d.resident_blocks <= 0) d.resident_blocks = rtk_trace_levels_resident_blocks(d.scene, d.num_cus);
+    // The walk that carries a record's reflection ray is the one the next level waits for.
+    // With plenty of tiles per resident workgroup the chain of levels hides behind the other
+    // work and the ray shares its walk with the first lights (fewest instructions); on a small
+    // frame the chain IS the frame time and the ray walks alone (shortest chain).
+    static const char *first_env = getenv("RT_HIP_FIRST_LIGHTS");
+    const int shared_walk = d.scene.nl >= 4 ? 3 : 2;
+    d.frame.first_lights = tiles0 >= RT_CHAIN_BOUND_TILES_PER_WORKGROUP * d.resident_blocks ? shared_walk : 0;
+    if (first_env) d.frame.first_lights = std::max(0, std::min(atoi(first_env), shared_walk));
     const DevFrame &f = d.frame;
     HIP_TRY(ctx, hipMemsetAsync(f.cnt, 0, 2 * (size_t)(max_depth + 2) * sizeof(int), stream));
     HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, RT_COUNTER_SLOTS * sizeof(DevCounters), stream));
     HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, sizeof(DevSched), stream));
-    d.timed = ctx->profiling && stream == d.stream;
+    d.timed = ctx->profiling;
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
     const int blocks = std::max(1, std::min({(P + 255) / 256, d.num_cus * 8, RT_COUNTER_SLOTS}));
     rtk_setup_camera(d.scene, dc, stream);
@@ -551,8 +585,6 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
         }
     } else {
         // Every level in one launch of resident workgroups (k_trace_levels).
-        if (d.resident_blocks <= 0) d.resident_blocks = rtk_trace_levels_resident_blocks(d.scene, d.num_cus);
-        const int tiles0 = (P + 255) / 256;
         rtk_trace_levels(d.scene, f, std::max(1, std::min({2 * tiles0, d.resident_blocks, RT_COUNTER_SLOTS})), stream);
     }
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[2], stream));
@@ -730,7 +762,32 @@ int rt_render_rows_device(rt_ctx *ctx, const rt_camera *cam, int w, int h, int r
     ctx->last_h = h;
     ctx->copy_ms = ctx->gather_ms = 0.0;
     for (size_t i = 1; i < ctx->dev.size(); i++) ctx->dev[i].last_P = 0;
-    return enqueue_rows(ctx, d, cam, w, h, row_begin, row_end, max_depth, dev_pixels_out,
+    return enqueue_rows(ctx, d, cam, w, h, contiguous_rows(row_begin, row_end), max_depth, dev_pixels_out,
+                        hip_stream ? static_cast<hipStream_t>(hip_stream) : d.stream);
+}
+
+int rt_band_rows(int height, int band_rows, int part, int parts)
+{
+    if (height < 0 || band_rows <= 0 || parts <= 0 || part < 0 || part >= parts) return RT_ERR_INVALID_ARG;
+    return rows_of_part(height, band_rows, part, parts);
+}
+
+int rt_render_bands_device(rt_ctx *ctx, const rt_camera *cam, int w, int h, int band_rows, int part, int parts,
+                           int max_depth, int32_t *dev_pixels_out, void *hip_stream)
+{
+    int rc = check_render_args(ctx, cam, w, h, max_depth);
+    if (rc != RT_OK) return rc;
+    if (band_rows <= 0 || parts <= 0 || part < 0 || part >= parts)
+        return fail(ctx, RT_ERR_INVALID_ARG, "bad band partition: %d rows per band, part %d of %d", band_rows, part, parts);
+    const RowSet rs{0, rows_of_part(h, band_rows, part, parts), band_rows, parts, part};
+    if (!dev_pixels_out && rs.rows > 0) return fail(ctx, RT_ERR_INVALID_ARG, "dev_pixels_out is NULL");
+    DeviceState &d = ctx->dev[0];
+    ctx->last_was_rows_device = true;
+    ctx->last_w = w;
+    ctx->last_h = h;
+    ctx->copy_ms = ctx->gather_ms = 0.0;
+    for (size_t i = 1; i < ctx->dev.size(); i++) ctx->dev[i].last_P = 0;
+    return enqueue_rows(ctx, d, cam, w, h, rs, max_depth, dev_pixels_out,
                         hip_stream ? static_cast<hipStream_t>(hip_stream) : d.stream);
 }
 
@@ -783,7 +840,7 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, in
             }
             target = d.out;
         }
-        if ((rc = enqueue_rows(ctx, d, cam, w, h, y0, y1, max_depth, target, d.stream)) != RT_OK) return rc;
+        if ((rc = enqueue_rows(ctx, d, cam, w, h, contiguous_rows(y0, y1), max_depth, target, d.stream)) != RT_OK) return rc;
     }
     // Gather: every other device writes its block into device 0's frame (one copy per
     // device, each over its own link), then one copy to the host.

@@ -94,7 +94,11 @@ struct DevCamera {
     float tan_h;     // (float)Math.Tan(angleH / 2)
     float tan_v;     // (float)Math.Tan(angleV / 2)
     int width, height;
-    int row_begin, row_end;
+    // The rows of this render call: local row l (0 <= l < rows, row l of the output block) is row
+    //   row_begin + ((l / band) * parts + part) * band + l % band
+    // of the frame: every parts-th band of `band` rows.  A contiguous block is parts = 1, part = 0.
+    int row_begin, rows;
+    int band, parts, part;
 };
 
 // Device-side counters of one render call.  DevFrame::counters holds RT_COUNTER_SLOTS of
@@ -153,6 +157,7 @@ struct DevFrame {
     int slots;             // P * (max_depth + 1)
     int max_depth;
     int mask_words;        // ceil(nl / 32), at least 1
+    int first_lights;      // lights traced in the same walk as a record's reflection ray (rt_kernels.hip, walks_of)
 };
 
 // Launch wrappers (rt_kernels.hip).  All enqueue on `stream` and return at once.

@@ -210,23 +210,23 @@ __device__ __forceinline__ void store_record(float4 *dst, const f4raw v)
 // for the level schedule: at most LCMAX rays per walk, where LCMAX = 4 in scenes with four or
 // more lights and 2 otherwise (with few lights the two-ray instance needs far fewer registers
 // and its rays are close enough to share one selection of spheres).  Walk 0 of a reflecting
-// record carries the reflection ray and its first LCMAX - 1 lights (LCMAX 2: both lights, three
-// rays); the other walks take the remaining lights in aligned groups of LCMAX, after one short
-// walk up to the first multiple of LCMAX if need be.  A walk's lights never straddle a 32-bit
-// word of the occlusion mask.
+// record carries the reflection ray and its first `first` lights (DevFrame::first_lights: LCMAX - 1,
+// with LCMAX 2 both lights, i.e. three rays; or 0, which makes the walk that has successors as
+// short as possible); the other walks take the remaining lights in aligned groups of LCMAX,
+// after one short walk up to the first multiple of LCMAX if need be.  A walk's lights never
+// straddle a 32-bit word of the occlusion mask.
 __host__ __device__ __forceinline__ int walk_lcmax(int nl) { return nl >= 4 ? 4 : 2; }
-__host__ __device__ __forceinline__ int walk_first_lights(int lcmax) { return lcmax >= 4 ? 3 : 2; }
-__host__ __device__ __forceinline__ int walks_of(bool reflecting, int nl)
+__host__ __device__ __forceinline__ int walks_of(bool reflecting, int nl, int first)
 {
-    const int g = walk_lcmax(nl), f = walk_first_lights(g);
+    const int g = walk_lcmax(nl), f = first;
     if (!reflecting) return (nl + g - 1) / g;
     if (nl <= f) return 1;
     const int a0 = (f + g - 1) / g * g;
     return 1 + (a0 > f ? 1 : 0) + (nl > a0 ? (nl - a0 + g - 1) / g : 0);
 }
-__device__ __forceinline__ void walk_lights(bool reflecting, int walk, int nl, int &l0, int &count)
+__device__ __forceinline__ void walk_lights(bool reflecting, int walk, int nl, int first, int &l0, int &count)
 {
-    const int g = walk_lcmax(nl), f = walk_first_lights(g);
+    const int g = walk_lcmax(nl), f = first;
     if (!reflecting) {
         l0 = walk * g;
         count = min(g, nl - l0);
@@ -307,7 +307,7 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
             store_record(&f.recA[slot], f4raw{hit[k].x, hit[k].y, hit[k].z, __int_as_float(prim[k])});
             store_record(&f.recB[slot], f4raw{view[k].x, view[k].y, view[k].z, __int_as_float(parent[k])});
             // Several walks OR their lights into the record's occlusion words: start from zero.
-            if (walks_of(is_a[k], s.nl) > 1)
+            if (walks_of(is_a[k], s.nl, f.first_lights) > 1)
                 for (int w = 0; w < f.mask_words; w++) store_word_through(&f.mask[(size_t)w * (size_t)f.slots + slot], 0u);
         }
     }
@@ -890,7 +890,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     __shared__ int blk[12];
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rows = cam.row_end - cam.row_begin;
+    const int rows = cam.rows;
     const int tiles_x = (cam.width + 31) >> 5, tiles_y = (rows + 31) >> 5;
     const int ntiles = tiles_x * tiles_y;
     const int nsp = s.ns_padded;
@@ -905,19 +905,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = tile / tiles_x;
         const int x0 = tx * 32 + (wave & 1) * 16 + (lane & 7) * 2;
-        const int y0 = cam.row_begin + ty * 32 + (wave >> 1) * 16 + (lane >> 3) * 2;
+        const int y0 = ty * 32 + (wave >> 1) * 16 + (lane >> 3) * 2;   // row of the output block
         bool inside[PRIM_PX];
-        int px[PRIM_PX], py[PRIM_PX];
+        int px[PRIM_PX], py[PRIM_PX], ly[PRIM_PX];
         f3 d[PRIM_PX];
         float a[PRIM_PX], best_t[PRIM_PX];
         int best_prim[PRIM_PX];   // host index of the closest sphere so far
 #pragma unroll
         for (int k = 0; k < PRIM_PX; k++) {
             const int x = x0 + (k & 1), y = y0 + (k >> 1);
-            inside[k] = x < cam.width && y < cam.row_end;
-            // Pixels outside the frame trace the frame's last pixel and write nothing.
+            inside[k] = x < cam.width && y < rows;
+            // Pixels outside the block trace the block's last pixel and write nothing.
             px[k] = x < cam.width ? x : cam.width - 1;
-            py[k] = y < cam.row_end ? y : cam.row_end - 1;
+            ly[k] = y < rows ? y : rows - 1;
+            py[k] = cam.row_begin + ((ly[k] / cam.band) * cam.parts + cam.part) * cam.band + ly[k] % cam.band;
             d[k] = primary_direction(cam, px[k], py[k]);
             a[k] = dot3(d[k], d[k]);
             best_t[k] = RT_FLT_MAX;
@@ -979,7 +980,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
                 if (triangle_t(e1, e2, sub3(o, v0), d[k], t)) closest_offer(c, t, cload(s.tri_orig, j));
             }
             const bool hit = inside[k] && c.prim != INT_MAX;
-            const int pix = (py[k] - cam.row_begin) * cam.width + px[k];
+            const int pix = ly[k] * cam.width + px[k];
             rec_valid[k] = hit;
             rec_prim[k] = hit ? c.prim : 0;
             rec_parent[k] = pix;
@@ -1205,7 +1206,7 @@ __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f,
     const int nl = s.nl;
     const bool with_sec = SEC && walk == 0;
     int l0, count;
-    walk_lights(SEC, walk, nl, l0, count);
+    walk_lights(SEC, walk, nl, f.first_lights, l0, count);
 #define RT_WALK(LC_, SEC_) trace_chunk<LC_, SEC_, (LCMAX >= 4), MULTI>(s, L, hit, view, normal, l0, word, sec, sec_dir, ltc, pc)
     bool done = false;
     if constexpr (LCMAX >= 4) {
@@ -1231,7 +1232,7 @@ __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f,
 #undef RT_WALK
     if (active && count > 0) {
         uint32_t *mw = &f.mask[(size_t)(l0 >> 5) * (size_t)f.slots + slot];
-        if (walks_of(SEC, nl) == 1) *mw = word;   // the only writer of the record's (single) word
+        if (walks_of(SEC, nl, f.first_lights) == 1) *mw = word;   // the only writer of the record's (single) word
         else if (word) atomicOr(mw, word);         // zeroed when the record was written
     }
     if (active) {
@@ -1282,7 +1283,7 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
     TestCount tc = {0, 0, 0, 0, 0, 0};
     PhaseClock pc = {};
     // Workgroup-uniform trip count: the sphere chunks are staged between barriers.
-    const int walks = walks_of(SEC, s.nl);
+    const int walks = walks_of(SEC, s.nl, f.first_lights);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
         for (int walk = 0; walk < walks; walk++) trace_tile<SEC, LCMAX, MULTI>(s, f, L, blk, level, tile, n, walk, tc, pc);
     flush_test_counts(f, cnt_sh, tc);
@@ -1348,7 +1349,7 @@ k_trace_levels(DevScene s, DevFrame f)
     DevSched *const sc = f.sched;
     const int D = f.max_depth;
     // Plain jobs of a level: every walk of its B tiles and the walks after the first of its A tiles.
-    const int walks_a = walks_of(true, s.nl), walks_b = walks_of(false, s.nl);
+    const int walks_a = walks_of(true, s.nl, f.first_lights), walks_b = walks_of(false, s.nl, f.first_lights);
     bool staged = false;
     TestCount tc = {0, 0, 0, 0, 0, 0};
     PhaseClock pc = {};
@@ -1613,8 +1614,7 @@ static bool multi_chunk(const DevScene &s) { return s.ns_padded > SPH_CHUNK; }
 void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels, int grid_blocks,
                  hipStream_t stream)
 {
-    const int rows = cam.row_end - cam.row_begin;
-    const int ntiles = ((cam.width + 31) / 32) * ((rows + 31) / 32);  // 32x32 pixels per workgroup trip
+    const int ntiles = ((cam.width + 31) / 32) * ((cam.rows + 31) / 32);  // 32x32 pixels per workgroup trip
     const dim3 g(ntiles < grid_blocks ? ntiles : grid_blocks), b(256);
     if (multi_chunk(s)) hipLaunchKernelGGL(k_primary<true>, g, b, 0, stream, s, cam, f, pixels);
     else hipLaunchKernelGGL(k_primary<false>, g, b, 0, stream, s, cam, f, pixels);

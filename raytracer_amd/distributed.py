@@ -1,12 +1,15 @@
-"""One process per GPU: row partition of the frame and the framebuffer gather.
+"""One process per GPU: partition of the frame's rows and the framebuffer gather.
 
-The frame is split into contiguous blocks of rows, one per rank — the image-space
-partition the reference applies to its thread pool (Parallel.For over rows,
-/root/reference/MyApplication.cs:408).  Pixels are independent, so the only exchange is
-the hand-off of the finished blocks to the presenting rank: one gather per frame, RCCL
-(torch.distributed backend "nccl") over xGMI between GPUs, gloo between CPU processes
-in the tests.  Receive buffers are row slices of rank 0's frame, so the collective
-writes each block where Surface.pixels expects it.
+The frame is cut into bands of BAND_ROWS rows and rank r of G takes the bands r, r + G,
+r + 2G, ... — an image-space partition like the one the reference applies to its thread pool
+(Parallel.For over rows, /root/reference/MyApplication.cs:408), interleaved because rows cost
+very different amounts (mirror spheres, the reflecting ceiling) and the reference's pool
+balances them dynamically while ranks cannot.  Pixels are independent, so the only exchange
+is the hand-off of the finished blocks to the presenting rank: one gather per frame, RCCL
+(torch.distributed backend "nccl") over xGMI between GPUs, gloo between CPU processes in the
+tests, followed on rank 0 by one row permutation that puts the bands where Surface.pixels
+expects them.  ``interleave=False`` gives contiguous blocks, whose receive buffers are row
+slices of rank 0's frame (no permutation).
 """
 from __future__ import annotations
 
@@ -15,12 +18,25 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
+BAND_ROWS = 16   # one wave of the primary kernel covers 16 x 16 pixels
+
 
 def row_block(height: int, rank: int, world: int) -> Tuple[int, int]:
     """Rows [begin, end) of rank `rank`: blocks differ by at most one row and tile [0, height)."""
     if not 0 <= rank < world:
         raise ValueError(f"rank {rank} outside [0, {world})")
     return (height * rank) // world, (height * (rank + 1)) // world
+
+
+def band_rows_of(height: int, rank: int, world: int, band_rows: int = BAND_ROWS) -> List[int]:
+    """Frame rows of rank `rank` in the interleaved partition, in the order of its block."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside [0, {world})")
+    rows: List[int] = []
+    bands = (height + band_rows - 1) // band_rows
+    for b in range(rank, bands, world):
+        rows.extend(range(b * band_rows, min(height, (b + 1) * band_rows)))
+    return rows
 
 
 class FrameGatherer:
@@ -31,21 +47,47 @@ class FrameGatherer:
     """
 
     def __init__(self, width: int, height: int, rank: int, world: int, device: torch.device,
-                 group: Optional[dist.ProcessGroup] = None):
+                 group: Optional[dist.ProcessGroup] = None, interleave: bool = True,
+                 band_rows: int = BAND_ROWS):
         self.width, self.height, self.rank, self.world, self.group = width, height, rank, world, group
+        self.band_rows = band_rows
+        self.interleave = interleave and world > 1
+        self.frame: Optional[torch.Tensor] = None
+        self._recv: Optional[List[torch.Tensor]] = None
+        self._perm: Optional[torch.Tensor] = None
+        # Rendering, the collective and the row permutation are ordered on ONE stream of this
+        # gatherer's own (the library's default stream is ordered against nothing).
+        self.stream = torch.cuda.Stream(device) if device.type == "cuda" else None
+        if rank == 0:
+            self.frame = torch.zeros((height, width), dtype=torch.int32, device=device)
+        if world == 1:
+            self.rows = height
+            self.block = self.frame
+            self._send = self.frame
+            self.equal = True
+            return
+        if self.interleave:
+            mine = [band_rows_of(height, r, world, band_rows) for r in range(world)]
+            self.rows = len(mine[rank])
+            tall = max(len(m) for m in mine)
+            self.equal = False
+            self._send = torch.zeros((tall, width), dtype=torch.int32, device=device)
+            self.block = self._send[: self.rows]
+            if rank == 0:
+                stacked = torch.zeros((world, tall, width), dtype=torch.int32, device=device)
+                self._stacked = stacked
+                self._recv = [stacked[r] for r in range(world)]
+                # frame row y comes from row perm[y] of the stacked blocks
+                perm = torch.empty(height, dtype=torch.int64)
+                for r, m in enumerate(mine):
+                    perm[torch.tensor(m, dtype=torch.int64)] = r * tall + torch.arange(len(m), dtype=torch.int64)
+                self._perm = perm.to(device)
+            return
         blocks = [row_block(height, r, world) for r in range(world)]
         y0, y1 = blocks[rank]
         self.rows = y1 - y0
         self.equal = len({b - a for a, b in blocks}) == 1
-        self.frame: Optional[torch.Tensor] = None
-        self._recv: Optional[List[torch.Tensor]] = None
         self._blocks = blocks
-        if rank == 0:
-            self.frame = torch.zeros((height, width), dtype=torch.int32, device=device)
-        if world == 1:
-            self.block = self.frame
-            self._send = self.frame
-            return
         if self.equal:
             # Rank 0 renders straight into its slice of the frame; the others into a block.
             self._send = (self.frame[y0:y1] if rank == 0
@@ -66,19 +108,40 @@ class FrameGatherer:
         """Enqueue the gather of all blocks to rank 0 (one collective per frame)."""
         if self.world == 1:
             return self.frame
-        dist.gather(self._send, self._recv if self.rank == 0 else None, dst=0, group=self.group)
-        if self.rank == 0 and not self.equal:
-            for (a, b), buf in zip(self._blocks, self._recv):
-                self.frame[a:b].copy_(buf[: b - a])
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                self._gather()
+        else:
+            self._gather()
         return self.frame
 
+    def _gather(self) -> None:
+        dist.gather(self._send, self._recv if self.rank == 0 else None, dst=0, group=self.group)
+        if self.rank == 0:
+            if self.interleave:
+                torch.index_select(self._stacked.view(-1, self.width), 0, self._perm, out=self.frame)
+            elif not self.equal:
+                for (a, b), buf in zip(self._blocks, self._recv):
+                    self.frame[a:b].copy_(buf[: b - a])
 
-def render_frame(ctx, camera, width: int, height: int, max_depth: int, gatherer: FrameGatherer,
-                 stream: Optional["torch.cuda.Stream"] = None) -> Optional[torch.Tensor]:
-    """One distributed Render(): this rank's rows through rt_render_rows_device, then the
-    gather.  Returns rank 0's frame tensor (device memory), None on the other ranks."""
-    y0, y1 = row_block(height, gatherer.rank, gatherer.world)
-    s = stream if stream is not None else torch.cuda.current_stream()
-    ctx.render_rows_device(camera, width, height, y0, y1, max_depth, gatherer.block.data_ptr(),
-                           s.cuda_stream)
+
+def render_block(ctx, camera, width: int, height: int, max_depth: int, gatherer: FrameGatherer) -> None:
+    """Enqueue this rank's part of the frame into ``gatherer.block`` (device memory) on the
+    gatherer's stream."""
+    g = gatherer
+    stream_handle = g.stream.cuda_stream if g.stream is not None else 0
+    if g.interleave:
+        ctx.render_bands_device(camera, width, height, g.band_rows, g.rank, g.world, max_depth,
+                                g.block.data_ptr(), stream_handle)
+    else:
+        y0, y1 = row_block(height, g.rank, g.world)
+        ctx.render_rows_device(camera, width, height, y0, y1, max_depth, g.block.data_ptr(), stream_handle)
+
+
+def render_frame(ctx, camera, width: int, height: int, max_depth: int,
+                 gatherer: FrameGatherer) -> Optional[torch.Tensor]:
+    """One distributed Render(): this rank's rows, then the gather, both enqueued on
+    ``gatherer.stream`` (synchronise it, or make your stream wait for it, before reading).
+    Returns rank 0's frame tensor (device memory), None on the other ranks."""
+    render_block(ctx, camera, width, height, max_depth, gatherer)
     return gatherer.gather()

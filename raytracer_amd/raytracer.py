@@ -97,6 +97,14 @@ class RenderContext:
             self._ctx, C.byref(camera.as_struct()), width, height, row_begin, row_end, max_depth,
             C.c_void_p(dev_ptr), C.c_void_p(stream)))
 
+    def render_bands_device(self, camera: Camera, width: int, height: int, band_rows: int,
+                            part: int, parts: int, max_depth: int, dev_ptr: int, stream: int = 0) -> None:
+        """rt_render_bands_device: every parts-th band of band_rows rows, starting with band
+        `part`, written one after the other to dev_ptr."""
+        self._check(self._lib.rt_render_bands_device(
+            self._ctx, C.byref(camera.as_struct()), width, height, band_rows, part, parts, max_depth,
+            C.c_void_p(dev_ptr), C.c_void_p(stream)))
+
     def stats(self) -> dict:
         st = abi.rt_stats()
         self._check(self._lib.rt_get_stats(self._ctx, C.byref(st)))

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     lib = abi.load_library()
     for name in declared_functions():
         assert getattr(lib, name) is not None, name
-    assert lib.rt_api_version() == 2
+    assert lib.rt_api_version() == 3
 
 
 def test_struct_sizes_match_the_header_layout():

@@ -23,20 +23,21 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _worker(rank: int, world: int, port: int, w: int, h: int, outdir: str):
+def _worker(rank: int, world: int, port: int, w: int, h: int, interleave: bool, outdir: str):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as O
     from raytracer_amd import Camera, default_scene
-    from raytracer_amd.distributed import FrameGatherer, row_block
+    from raytracer_amd.distributed import FrameGatherer, band_rows_of, row_block
     fs, cam = default_scene().flatten(), Camera()
-    g = FrameGatherer(w, h, rank, world, torch.device("cpu"))
-    y0, y1 = row_block(h, rank, world)
-    img, _ = O.render(fs, cam, w, h, rows=(y0, y1), nthreads=1)
+    g = FrameGatherer(w, h, rank, world, torch.device("cpu"), interleave=interleave, band_rows=4)
+    img, _ = O.render(fs, cam, w, h, nthreads=1)
+    mine = band_rows_of(h, rank, world, 4) if interleave else list(range(*row_block(h, rank, world)))
+    assert g.rows == len(mine)
     for _ in range(2):  # two frames in a row reuse the buffers
-        g.block.copy_(torch.from_numpy(img[y0:y1]))
+        g.block.copy_(torch.from_numpy(img[mine]))
         frame = g.gather()
     if rank == 0:
         np.save(os.path.join(outdir, "frame.npy"), frame.numpy())
@@ -46,11 +47,12 @@ def _worker(rank: int, world: int, port: int, w: int, h: int, outdir: str):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,h", [(2, 48), (2, 37), (3, 50)])
-def test_gather_reassembles_the_frame(tmp_path, oracle, world, h):
+@pytest.mark.parametrize("world,h,interleave", [(2, 48, False), (2, 37, False), (3, 50, False),
+                                                (2, 48, True), (2, 37, True), (3, 50, True), (3, 7, True)])
+def test_gather_reassembles_the_frame(tmp_path, oracle, world, h, interleave):
     from raytracer_amd import Camera, default_scene
     w = 64
-    mp.spawn(_worker, args=(world, _free_port(), w, h, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), w, h, interleave, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "frame.npy")
     ref, _ = oracle.render(default_scene().flatten(), Camera(), w, h)
     assert np.array_equal(got, ref)
@@ -67,3 +69,14 @@ def test_row_blocks_tile_the_frame():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         row_block(10, 2, 2)
+
+
+def test_bands_tile_the_frame():
+    from raytracer_amd.distributed import band_rows_of
+    for h in (1, 7, 37, 1080, 2160):
+        for world in (1, 2, 3, 8):
+            for band in (1, 4, 16):
+                rows = [band_rows_of(h, r, world, band) for r in range(world)]
+                assert sorted(y for m in rows for y in m) == list(range(h))
+                sizes = [len(m) for m in rows]
+                assert max(sizes) - min(sizes) <= band

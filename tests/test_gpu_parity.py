@@ -150,6 +150,34 @@ def test_row_ranges_tile_the_frame(ctx, oracle):
     assert_parity(full, ref, "row ranges")
 
 
+def test_interleaved_bands_tile_the_frame(ctx):
+    """rt_render_bands_device: the parts of an interleaved partition, put back, are the frame."""
+    import torch
+    from raytracer_amd import abi
+    from raytracer_amd.distributed import band_rows_of
+    lib = abi.load_library()
+    fs = scene_1k().flatten()
+    ctx.set_scene(fs)
+    cam, depth = Camera(), 3
+    for (w, h, band, parts) in [(200, 120, 16, 3), (97, 53, 16, 8), (64, 40, 4, 2), (33, 5, 16, 4)]:
+        full = ctx.render(cam, w, h, depth)
+        got = np.zeros_like(full)
+        for part in range(parts):
+            rows = band_rows_of(h, part, parts, band)
+            assert lib.rt_band_rows(h, band, part, parts) == len(rows)
+            buf = torch.full((max(len(rows), 1), w), -1, dtype=torch.int32, device="cuda")
+            ctx.render_bands_device(cam, w, h, band, part, parts, depth, buf.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            if rows:
+                got[rows] = buf.cpu().numpy()[: len(rows)]
+        assert np.array_equal(got, full), (w, h, band, parts)
+    with pytest.raises(RtError):
+        ctx.render_bands_device(cam, 8, 8, 0, 0, 1, depth, 0, 0)
+    with pytest.raises(RtError):
+        ctx.render_bands_device(cam, 8, 8, 16, 2, 2, depth, 0, 0)
+
+
 def test_errors_follow_the_convention(ctx):
     fresh = RenderContext()
     with pytest.raises(RtError) as e:

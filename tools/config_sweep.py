@@ -23,24 +23,32 @@ sys.path.insert(0, ROOT)
 from raytracer_amd import Camera, RenderContext, default_scene, scene_1k, scene_64k  # noqa: E402
 
 
-def time_rows(ctx, cam, w, h, depth, rows, frames, profile=True):
-    """ms per call of rt_render_rows_device over `rows` = [(y0, y1), ...] rendered back to back."""
-    bufs = [torch.empty((y1 - y0, w), dtype=torch.int32, device="cuda") for y0, y1 in rows]
-    stream = torch.cuda.current_stream().cuda_stream
+def time_rows(ctx, cam, w, h, depth, rows, frames, profile=True, bands=None):
+    """ms per render call, each part rendered alone, back to back: `rows` = [(y0, y1), ...]
+    contiguous blocks, or with bands = (band_rows, parts) the parts of the interleaved partition."""
+    if bands:
+        band, parts = bands
+        jobs = [(lambda buf, s, p=p: ctx.render_bands_device(cam, w, h, band, p, parts, depth, buf.data_ptr(), s),
+                 (h + parts - 1) // parts + band) for p in range(parts)]
+    else:
+        jobs = [(lambda buf, s, y0=y0, y1=y1: ctx.render_rows_device(cam, w, h, y0, y1, depth, buf.data_ptr(), s),
+                 y1 - y0) for y0, y1 in rows]
+    stream = torch.cuda.Stream()
     out = []
-    for (y0, y1), buf in zip(rows, bufs):
+    for call, nrows in jobs:
+        buf = torch.empty((nrows, w), dtype=torch.int32, device="cuda")
         ctx.set_profiling(False)
-        ctx.render_rows_device(cam, w, h, y0, y1, depth, buf.data_ptr(), stream)
+        call(buf, stream.cuda_stream)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(frames):
-            ctx.render_rows_device(cam, w, h, y0, y1, depth, buf.data_ptr(), stream)
+            call(buf, stream.cuda_stream)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / frames * 1e3
         st = None
         if profile:
             ctx.set_profiling(True)
-            ctx.render_rows_device(cam, w, h, y0, y1, depth, buf.data_ptr(), stream)
+            call(buf, stream.cuda_stream)
             st = ctx.stats()
         out.append((ms, st))
     return out
@@ -83,11 +91,12 @@ def main():
         ctx.set_scene(scene_1k().flatten())
         w, h, depth = 3840, 2160, 4
         (full_ms, _), = time_rows(ctx, cam, w, h, depth, [(0, h)], args.frames * 4, profile=False)
-        for G in (2, 4, 8):
+        for G, banded in ((2, False), (4, False), (8, False), (2, True), (4, True), (8, True)):
             rows = [((h * r) // G, (h * (r + 1)) // G) for r in range(G)]
-            res = time_rows(ctx, cam, w, h, depth, rows, args.frames * 4)
+            res = time_rows(ctx, cam, w, h, depth, rows, args.frames * 4, bands=(16, G) if banded else None)
             ms = [round(m, 4) for m, _ in res]
-            print(json.dumps({"config": f"C3 frame as {G} contiguous row blocks", "full_frame_ms": round(full_ms, 4),
+            what = f"{G} interleaved parts (bands of 16 rows)" if banded else f"{G} contiguous row blocks"
+            print(json.dumps({"config": f"C3 frame as {what}", "full_frame_ms": round(full_ms, 4),
                               "block_ms": ms, "max_ms": max(ms), "sum_ms": round(sum(ms), 4),
                               "primary_ms": [round(st["primary_ms"], 3) for _, st in res],
                               "trace_ms": [round(st["trace_ms"], 3) for _, st in res],
