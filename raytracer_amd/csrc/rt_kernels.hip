@@ -256,6 +256,22 @@ __device__ __forceinline__ void store_word_through(uint32_t *dst, uint32_t v)
     asm volatile("global_store_dword %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
 }
 
+// The two halves of a hit record with device-scope loads (sc1: served from memory, not from
+// whatever this XCD's L2 or this CU's L1 may hold of the line): the counterpart of store_record
+// for records that another workgroup wrote earlier in the same launch.
+__device__ __forceinline__ void load_record(const float4 *a, const float4 *b, float4 &ra, float4 &rb)
+{
+    f4raw va, vb;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %3, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(va), "=&v"(vb)
+                 : "v"(a), "v"(b)
+                 : "memory");
+    ra = make_float4(va.x, va.y, va.z, va.w);
+    rb = make_float4(vb.x, vb.y, vb.z, vb.w);
+}
+
 // Append up to N new hit records per thread to level `level`, with ONE atomic per queue per
 // WORKGROUP: a single counter word takes only ~90 returning atomics per microsecond, and a
 // frame appends hundreds of thousands of waves' worth of records.  Every thread of the
@@ -1193,7 +1209,8 @@ __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f,
     const bool active = i < n;
     const int ii = active ? i : n - 1;
     const int slot = SEC ? (level * f.P + ii) : ((level + 1) * f.P - 1 - ii);
-    const float4 ra = f.recA[slot], rb = f.recB[slot];
+    float4 ra, rb;
+    load_record(&f.recA[slot], &f.recB[slot], ra, rb);
     const f3 hit = xyz(ra), view = xyz(rb);
     const int prim = __float_as_int(ra.w);
     const int type = __float_as_int(cload(s.mat, 3 * prim + 1).w) & RT_MF_TYPE_MASK;
@@ -1309,10 +1326,10 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
 //     open_level = k+1.  No write-back fence is needed.
 //   * a taker (thread 0) reads open_level with a device-scope load on every claim and reads a
 //     newly opened level's record counts before it hands tiles of that level to the workgroup.
-//     No cache invalidation is needed either: nobody reads a slot of a level before the level is
-//     open, and the levels' slot ranges start at multiples of RT_LEVEL_ALIGN slots, so no cache
-//     line of recA / recB / mask holds slots of two levels: a line that a workgroup reads from
-//     an open level cannot have been cached, by any XCD, before its last write of this launch.
+//     No cache invalidation is needed either: the records are read with device-scope loads
+//     (load_record), the occlusion words are zeroed with device-scope stores and updated with
+//     device-scope atomics, and the levels' slot ranges start at multiples of RT_LEVEL_ALIGN
+//     slots, so no cache line of a per-slot array holds slots of two levels.
 // The chain ends at the first open level without A records (level max_depth never has any);
 // a workgroup leaves when the chain has ended and no B tile is left to claim.  A workgroup
 // that waits longer than SCHED_SPIN_LIMIT polls for a level to open sets sched->error and
