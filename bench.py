@@ -64,6 +64,19 @@ def cpu_baseline(flat, cam, row_step: int = 1) -> dict:
     }
 
 
+def pmc_traffic() -> tuple:
+    """HBM bytes per launch of the traversal kernel on this workload, from the committed
+    rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot be collected from inside this
+    process); (None, reason) when the summary is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_v10_trace_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return int(d["traffic_bytes_per_launch"]), "profiles/r01_v10_trace_traffic.json (rocprofv3 --pmc, one GPU)"
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC summary committed"
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,7 +184,8 @@ def main() -> None:
             "roofline": {
                 "bound": "valu-fp32", "kernel": "k_trace_levels (every level of the frame in one launch)",
                 "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+                "traffic": pmc_traffic()[0] if world == 1 else None, "traffic_source": pmc_traffic()[1],
                 "algorithmic_flop_per_launch": trace_flop / world,
                 "kernel_ms": round(trace_ms, 4),
                 "executed": {"flop_per_launch": executed_flop / world, "tflops": round(executed, 3),
