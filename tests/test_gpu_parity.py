@@ -243,6 +243,23 @@ def test_config5_64k_spheres_16_lights_depth8(ctx, oracle):
         assert st[k] == cnt[k], k
 
 
+@pytest.mark.parametrize("nspheres,nl,depth,size", [(1500, 2, 3, (160, 90)), (1025, 5, 2, (96, 54)),
+                                                    (2048, 0, 2, (64, 36)), (132000, 2, 2, (40, 24))])
+def test_chunked_scenes(ctx, oracle, nspheres, nl, depth, size):
+    """Scenes of more than one LDS chunk of spheres: a ragged last chunk, exactly two chunks,
+    and more chunks than one piece of chunk balls holds (128)."""
+    s = synthetic_scene(nspheres, radius=(0.004, 0.05) if nspheres > 10000 else (0.02, 0.1), seed=23 + nspheres)
+    s.lights.clear()
+    for i in range(nl):
+        s.Add(Light(-2.5 + 1.1 * i, -1.0 - 0.1 * i, 0.6 + 0.5 * i))
+    w, h = size
+    gpu, ref, cnt = both(ctx, oracle, s, Camera(), w, h, depth)
+    assert_parity(gpu, ref, f"{nspheres} spheres, {nl} lights")
+    st = ctx.stats()
+    for k in ("rays_shadow", "rays_secondary", "shaded_hits", "sphere_tests", "plane_tests"):
+        assert st[k] == cnt[k], k
+
+
 def test_two_device_states_split_rows_and_gather(oracle):
     """rt_create with two device entries (the same GPU twice on a one-GPU box): the frame is
     split into two row blocks, the second is gathered into the first device's frame."""
