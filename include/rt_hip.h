@@ -196,6 +196,23 @@ int rt_render(rt_ctx *ctx, const rt_camera *camera, int width, int height,
               int max_depth, int32_t *pixels_out);
 
 /*
+ * Page-lock the host's framebuffer so that rt_render copies device -> pixels_out in one DMA
+ * instead of device -> internal pinned staging -> memcpy (at 3840x2160 the extra copy costs
+ * about as much as rendering the frame).  `pixels` .. `pixels + count` must stay allocated
+ * and at the same address until rt_unpin_pixels or rt_destroy: in the reference that is
+ * Surface.pixels, allocated once in the constructor and never reallocated (surface.cs:14-19);
+ * a C# host pins the array with GCHandle.Alloc(pixels, GCHandleType.Pinned) and passes
+ * AddrOfPinnedObject().  rt_render uses the direct path whenever pixels_out .. pixels_out +
+ * width*height lies inside the registered range, the staged path otherwise.  One range per
+ * context; registering another replaces it.  Where the system refuses to page-lock user
+ * memory the call fails with RT_ERR_HIP and changes nothing: rt_render keeps working through
+ * its staged copy.  No counterpart in the reference (the CPU loop
+ * writes the array directly, MyApplication.cs:420).
+ */
+int rt_pin_pixels(rt_ctx *ctx, int32_t *pixels, int64_t count);
+int rt_unpin_pixels(rt_ctx *ctx);
+
+/*
  * Render rows [row_begin, row_end) of a width x height frame on the context's
  * first device into device memory: dev_pixels_out points to (row_end-row_begin) *
  * width int32 on that device; element (y - row_begin) * width + x is pixel (x, y)

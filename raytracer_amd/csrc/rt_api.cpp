@@ -61,6 +61,9 @@ struct rt_ctx {
     uint32_t textures_loaded = 0;  // bit i: slot i holds an image
     int32_t *staging = nullptr;    // pinned host staging for rt_render
     size_t cap_staging = 0;
+    int32_t *pinned = nullptr;     // the host's own framebuffer, page-locked by rt_pin_pixels
+    void *pinned_base = nullptr;   // start of the registered pages
+    size_t pinned_count = 0;
     double copy_ms = 0.0, gather_ms = 0.0;
     std::vector<int> last_rows;    // row split of the last rt_render (n_dev + 1 entries)
     int last_w = 0, last_h = 0;
@@ -674,6 +677,7 @@ void rt_destroy(rt_ctx *ctx)
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
     if (ctx->staging) (void)hipHostFree(ctx->staging);
+    if (ctx->pinned) (void)hipHostUnregister(ctx->pinned_base);
     delete ctx;
 }
 
@@ -816,7 +820,9 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, in
         HIP_TRY(ctx, hipMalloc((void **)&root.out, (size_t)total * sizeof(int32_t)));
         root.cap_out = (size_t)total;
     }
-    if ((size_t)total > ctx->cap_staging) {
+    const bool direct = ctx->pinned && pixels_out >= ctx->pinned &&
+                        (size_t)(pixels_out - ctx->pinned) + (size_t)total <= ctx->pinned_count;
+    if (!direct && (size_t)total > ctx->cap_staging) {
         if (ctx->staging) (void)hipHostFree(ctx->staging);
         ctx->staging = nullptr;
         ctx->cap_staging = 0;
@@ -866,13 +872,54 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, in
         }
         if (d.last_P > 0 && (rc = check_schedule(ctx, d)) != RT_OK) return rc;
     }
-    // D2H into pinned staging, then into the caller's (pageable) array.
+    // D2H straight into the caller's array when it is page-locked (rt_pin_pixels), else into
+    // pinned staging and from there into the caller's (pageable) array.
     const auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->staging, root.out, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost,
-                                root.stream));
+    HIP_TRY(ctx, hipMemcpyAsync(direct ? pixels_out : ctx->staging, root.out, (size_t)total * sizeof(int32_t),
+                                hipMemcpyDeviceToHost, root.stream));
     HIP_TRY(ctx, hipStreamSynchronize(root.stream));
-    memcpy(pixels_out, ctx->staging, (size_t)total * sizeof(int32_t));
+    if (!direct) memcpy(pixels_out, ctx->staging, (size_t)total * sizeof(int32_t));
     ctx->copy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
+int rt_unpin_pixels(rt_ctx *ctx)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (ctx->pinned) {
+        for (DeviceState &d : ctx->dev) {   // no copy into the range may be in flight
+            HIP_TRY(ctx, hipSetDevice(d.device));
+            HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+        }
+        void *p = ctx->pinned_base;
+        ctx->pinned = nullptr;
+        ctx->pinned_base = nullptr;
+        ctx->pinned_count = 0;
+        HIP_TRY(ctx, hipHostUnregister(p));
+    }
+    return RT_OK;
+}
+
+int rt_pin_pixels(rt_ctx *ctx, int32_t *pixels, int64_t count)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!pixels || count <= 0) return fail(ctx, RT_ERR_INVALID_ARG, "bad framebuffer range (%p, %lld)", (void *)pixels, (long long)count);
+    int rc = rt_unpin_pixels(ctx);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->dev[0].device));
+    // Whole pages: every page that holds a byte of the array (all of them are mapped).
+    const uintptr_t page = 4096, lo = (uintptr_t)pixels & ~(page - 1),
+                    hi = ((uintptr_t)(pixels + count) + page - 1) & ~(page - 1);
+    const hipError_t e = hipHostRegister((void *)lo, (size_t)(hi - lo), hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        // Some systems refuse to page-lock user memory; rt_render keeps using its staged copy.
+        (void)hipGetLastError();   // the failure must not linger as the process's last HIP error
+        return fail(ctx, RT_ERR_HIP, "hipHostRegister refused the framebuffer (%s); rt_render keeps staging its copy",
+                    hipGetErrorString(e));
+    }
+    ctx->pinned_base = (void *)lo;
+    ctx->pinned = pixels;
+    ctx->pinned_count = (size_t)count;
     return RT_OK;
 }
 

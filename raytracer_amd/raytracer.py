@@ -74,6 +74,18 @@ class RenderContext:
         self._check(self._lib.rt_set_texture(self._ctx, slot, img.ctypes.data, img.shape[1],
                                              img.shape[0]))
 
+    def pin_pixels(self, pixels: np.ndarray) -> None:
+        """rt_pin_pixels: page-lock a C-contiguous int32 array that later render(out=...) calls
+        write into (the caller keeps it alive until unpin_pixels() or close())."""
+        if pixels.dtype != np.int32 or not pixels.flags.c_contiguous:
+            raise ValueError("pixels must be a C-contiguous int32 array")
+        self._check(self._lib.rt_pin_pixels(self._ctx, pixels.ctypes.data, pixels.size))
+        self._pinned_keepalive = pixels
+
+    def unpin_pixels(self) -> None:
+        self._check(self._lib.rt_unpin_pixels(self._ctx))
+        self._pinned_keepalive = None
+
     def set_profiling(self, enable: bool) -> None:
         self._check(self._lib.rt_set_profiling(self._ctx, 1 if enable else 0))
 
@@ -134,6 +146,10 @@ class Raytracer:
         self.scene, self.camera, self.screen = scene, camera, screen
         self.max_depth = max_depth
         self.context = RenderContext(device_ids)
+        try:   # Surface.pixels is never reallocated (surface.cs:14-19); an optimisation only
+            self.context.pin_pixels(self.screen.pixels)
+        except RtError:
+            pass
         for slot, tex in enumerate(textures):
             self.context.set_texture(slot, tex)
         self.UpdateScene()

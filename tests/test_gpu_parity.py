@@ -2,8 +2,8 @@
 import numpy as np
 import pytest
 
-from raytracer_amd import (Camera, Light, Material, Plane, RenderContext, RtError, Scene, Sphere,
-                           Triangle, default_scene, scene_1k, synthetic_scene)
+from raytracer_amd import (Camera, Light, Material, Plane, Raytracer, RenderContext, RtError, Scene, Sphere,
+                           Surface, Triangle, default_scene, scene_1k, synthetic_scene)
 from tests.parity import assert_parity
 
 pytestmark = pytest.mark.gpu
@@ -176,6 +176,36 @@ def test_interleaved_bands_tile_the_frame(ctx):
         ctx.render_bands_device(cam, 8, 8, 0, 0, 1, depth, 0, 0)
     with pytest.raises(RtError):
         ctx.render_bands_device(cam, 8, 8, 16, 2, 2, depth, 0, 0)
+
+
+def test_pinned_framebuffer_takes_the_direct_copy(oracle):
+    """rt_pin_pixels: frames rendered into the registered array (whole or a sub-range) and into
+    an unregistered one are the same frames."""
+    fs, cam = default_scene().flatten(), Camera()
+    with RenderContext() as c:
+        c.set_scene(fs)
+        plain = c.render(cam, 320, 200, 5)
+        big = np.full(2 * 320 * 200 + 7, -1, dtype=np.int32)
+        try:
+            c.pin_pixels(big)
+        except RtError as e:   # this system does not page-lock user memory: the staged path must go on working
+            assert e.status == -4 and "hipHostRegister" in e.message
+        whole = c.render(cam, 320, 200, 5, out=big[: 320 * 200])
+        assert np.array_equal(whole.reshape(200, 320), plain)
+        part = c.render(cam, 320, 200, 5, out=big[320 * 200 + 3: 2 * 320 * 200 + 3])
+        assert np.array_equal(part.reshape(200, 320), plain) and (big[-4:] == -1).all()
+        other = c.render(cam, 320, 200, 5)          # not inside the range: staged path
+        assert np.array_equal(other, plain)
+        c.unpin_pixels()
+        assert np.array_equal(c.render(cam, 320, 200, 5, out=big[: 320 * 200]).reshape(200, 320), plain)
+        ref, _ = oracle.render(fs, cam, 320, 200, max_depth=5)
+        assert np.array_equal(plain, ref)
+    screen = Surface(96, 64)
+    rt = Raytracer(default_scene(), cam, screen)   # pins screen.pixels
+    rt.Render()
+    ref, _ = oracle.render(fs, cam, 96, 64, max_depth=5)
+    assert np.array_equal(screen.image(), ref)
+    rt.context.close()
 
 
 def test_errors_follow_the_convention(ctx):

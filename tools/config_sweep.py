@@ -87,6 +87,35 @@ def main():
     if "c5" in want:
         w, h = (int(v) for v in args.c5_size.split("x"))
         single("C5 64k spheres, 16 lights, 8 bounces", scene_64k().flatten(), w, h, 8, max(1, args.frames // 3))
+    if "host" in want:
+        # rt_render into host memory (what the C# host calls): pageable array vs page-locked array.
+        import numpy as np
+        ctx.set_scene(scene_1k().flatten())
+        ctx.set_profiling(False)
+        w, h, depth = 3840, 2160, 4
+        out = np.zeros(w * h, dtype=np.int32)
+        for pinned in (False, True):
+            if pinned:
+                try:
+                    ctx.pin_pixels(out)
+                except Exception as e:   # systems that do not page-lock user memory
+                    print(json.dumps({"config": "C3 through rt_render into host memory",
+                                      "framebuffer": "page-locked (rt_pin_pixels)", "refused": str(e)}), flush=True)
+                    break
+            ctx.render(cam, w, h, depth, out=out)
+            t0 = time.perf_counter()
+            for _ in range(args.frames * 2):
+                ctx.render(cam, w, h, depth, out=out)
+            ms = (time.perf_counter() - t0) / (args.frames * 2) * 1e3
+            ctx.set_profiling(True)
+            ctx.render(cam, w, h, depth, out=out)
+            st = ctx.stats()
+            ctx.set_profiling(False)
+            print(json.dumps({"config": "C3 through rt_render into host memory",
+                              "framebuffer": "page-locked (rt_pin_pixels)" if pinned else "pageable",
+                              "ms_per_frame": round(ms, 3), "kernel_ms": round(st["kernel_ms"], 3),
+                              "copy_ms": round(st["copy_ms"], 3)}), flush=True)
+        ctx.unpin_pixels()
     if "split" in want:
         ctx.set_scene(scene_1k().flatten())
         w, h, depth = 3840, 2160, 4
