@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--configs", default="c2,c3,c5,split")
     ap.add_argument("--frames", type=int, default=5)
     ap.add_argument("--c5-size", default="1920x1080")
+    ap.add_argument("--split-size", default="3840x2160", help="frame of the simulated row partitions")
     args = ap.parse_args()
     want = set(args.configs.split(","))
     cam = Camera()
@@ -118,14 +119,14 @@ def main():
         ctx.unpin_pixels()
     if "split" in want:
         ctx.set_scene(scene_1k().flatten())
-        w, h, depth = 3840, 2160, 4
+        (w, h), depth = (int(v) for v in args.split_size.split("x")), 4
         (full_ms, _), = time_rows(ctx, cam, w, h, depth, [(0, h)], args.frames * 4, profile=False)
         for G, banded in ((2, False), (4, False), (8, False), (2, True), (4, True), (8, True)):
             rows = [((h * r) // G, (h * (r + 1)) // G) for r in range(G)]
             res = time_rows(ctx, cam, w, h, depth, rows, args.frames * 4, bands=(16, G) if banded else None)
             ms = [round(m, 4) for m, _ in res]
             what = f"{G} interleaved parts (bands of 16 rows)" if banded else f"{G} contiguous row blocks"
-            print(json.dumps({"config": f"C3 frame as {what}", "full_frame_ms": round(full_ms, 4),
+            print(json.dumps({"config": f"{w}x{h} frame as {what}", "full_frame_ms": round(full_ms, 4),
                               "block_ms": ms, "max_ms": max(ms), "sum_ms": round(sum(ms), 4),
                               "primary_ms": [round(st["primary_ms"], 3) for _, st in res],
                               "trace_ms": [round(st["trace_ms"], 3) for _, st in res],
