@@ -22,6 +22,10 @@ namespace {
 // Below this many level-0 tiles per resident workgroup a frame is bound by its chain of levels.
 constexpr int RT_CHAIN_BOUND_TILES_PER_WORKGROUP = 8;
 
+// Counter slots + level schedule + two record counts per level (DevFrame::counters, sched, cnt).
+constexpr size_t FRAME_CONTROL_BYTES =
+    RT_COUNTER_SLOTS * sizeof(DevCounters) + sizeof(DevSched) + 2 * RT_DEV_MAX_LEVELS * sizeof(int);
+
 thread_local std::string g_create_error;
 
 struct DeviceState {
@@ -34,13 +38,11 @@ struct DeviceState {
     // scene
     DevScene scene{};
     std::vector<void *> scene_allocs;
-    float4 *cam_terms = nullptr;   // sph_cam, grp_cam, sup_cam, chk_cam in one allocation
     void *tex_mem[RT_MAX_TEXTURES] = {};
 
     // per-frame scratch
     DevFrame frame{};
     size_t cap_slots = 0, cap_mask = 0;
-    int cap_levels = 0;
     int32_t *out = nullptr;  // device framebuffer block of this device
     size_t cap_out = 0;
 
@@ -96,8 +98,6 @@ void free_scene(DeviceState &d)
 {
     for (void *p : d.scene_allocs) (void)hipFree(p);
     d.scene_allocs.clear();
-    if (d.cam_terms) (void)hipFree(d.cam_terms);
-    d.cam_terms = nullptr;
     const uchar4 *tex[RT_DEV_MAX_TEXTURES];
     int tw[RT_DEV_MAX_TEXTURES], th[RT_DEV_MAX_TEXTURES];
     memcpy(tex, d.scene.tex, sizeof tex);
@@ -115,14 +115,11 @@ void free_frame(DeviceState &d)
     if (d.frame.recB) (void)hipFree(d.frame.recB);
     if (d.frame.refl) (void)hipFree(d.frame.refl);
     if (d.frame.mask) (void)hipFree(d.frame.mask);
-    if (d.frame.cnt) (void)hipFree(d.frame.cnt);
-    if (d.frame.counters) (void)hipFree(d.frame.counters);
-    if (d.frame.sched) (void)hipFree(d.frame.sched);
+    if (d.frame.counters) (void)hipFree(d.frame.counters);   // counters, sched and cnt are one allocation
     if (d.out) (void)hipFree(d.out);
     d.frame = DevFrame{};
     d.out = nullptr;
     d.cap_slots = d.cap_mask = d.cap_out = 0;
-    d.cap_levels = 0;
 }
 
 template <typename T>
@@ -389,12 +386,6 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     if ((rc = upload(ctx, d, ps.light_pos, &sc.light_pos)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.light_col, &sc.light_col)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.class_prefix, &sc.class_prefix)) != RT_OK) return rc;
-    const size_t cam_entries = ps.sph.size() + ps.grp_f.size() + ps.sup_f.size() + ps.chk_f.size();
-    HIP_TRY(ctx, hipMalloc((void **)&d.cam_terms, std::max<size_t>(cam_entries * sizeof(float4), 16)));
-    sc.sph_cam = d.cam_terms;
-    sc.grp_cam = sc.sph_cam + ps.sph.size();
-    sc.sup_cam = sc.grp_cam + ps.grp_f.size();
-    sc.chk_cam = sc.sup_cam + ps.sup_f.size();
     sc.nsup_padded = (int)ps.sup_f.size();
     sc.nchk_padded = (int)ps.chk_f.size();
     sc.grp_rmax = ps.grp_rmax;
@@ -485,16 +476,15 @@ int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
         HIP_TRY(ctx, hipMalloc((void **)&d.frame.mask, slots * words * sizeof(uint32_t)));
         d.cap_mask = slots * words;
     }
-    if (levels + 1 > d.cap_levels) {
-        if (d.frame.cnt) (void)hipFree(d.frame.cnt);
-        d.frame.cnt = nullptr;
-        d.cap_levels = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&d.frame.cnt, 2 * (size_t)(levels + 1) * sizeof(int)));
-        d.cap_levels = levels + 1;
+    // What every render call zeroes, in one allocation so that it is one fill per frame:
+    // the counter slots, the level schedule, the record counts of every possible level.
+    if (!d.frame.counters) {
+        char *ctl = nullptr;
+        HIP_TRY(ctx, hipMalloc((void **)&ctl, FRAME_CONTROL_BYTES));
+        d.frame.counters = reinterpret_cast<DevCounters *>(ctl);
+        d.frame.sched = reinterpret_cast<DevSched *>(ctl + RT_COUNTER_SLOTS * sizeof(DevCounters));
+        d.frame.cnt = reinterpret_cast<int *>(ctl + RT_COUNTER_SLOTS * sizeof(DevCounters) + sizeof(DevSched));
     }
-    if (!d.frame.counters)
-        HIP_TRY(ctx, hipMalloc((void **)&d.frame.counters, RT_COUNTER_SLOTS * sizeof(DevCounters)));
-    if (!d.frame.sched) HIP_TRY(ctx, hipMalloc((void **)&d.frame.sched, sizeof(DevSched)));
     d.frame.P = (int)stride;
     d.frame.slots = (int)slots;
     d.frame.max_depth = max_depth;
@@ -569,13 +559,10 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     d.frame.first_lights = tiles0 >= RT_CHAIN_BOUND_TILES_PER_WORKGROUP * d.resident_blocks ? shared_walk : 0;
     if (first_env) d.frame.first_lights = std::max(0, std::min(atoi(first_env), shared_walk));
     const DevFrame &f = d.frame;
-    HIP_TRY(ctx, hipMemsetAsync(f.cnt, 0, 2 * (size_t)(max_depth + 2) * sizeof(int), stream));
-    HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, RT_COUNTER_SLOTS * sizeof(DevCounters), stream));
-    HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, sizeof(DevSched), stream));
+    HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, FRAME_CONTROL_BYTES, stream));
     d.timed = ctx->profiling;
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
     const int blocks = std::max(1, std::min({(P + 255) / 256, d.num_cus * 8, RT_COUNTER_SLOTS}));
-    rtk_setup_camera(d.scene, dc, stream);
     rtk_primary(d.scene, dc, f, dev_pixels, blocks, stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[1], stream));
     // RT_HIP_LEVEL_KERNELS=1 (profiling aid): one launch per queue per level on this stream,

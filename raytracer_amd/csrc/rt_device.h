@@ -13,8 +13,8 @@
 //   grp_f    float4 {P'x, P'y, P'z, W}       one bounding ball per group, same form
 //   sup_f, chk_f                             one bounding ball per RT_SUPER (64) spheres and per
 //                                            RT_CHUNK (1024) spheres: two coarser levels, same form
-//   sph_cam, grp_cam, sup_cam, chk_cam  float4 {p', -c''}  per frame: the filter's term for the
-//                                            camera origin
+// (The primary kernel turns the four filter arrays into {p', -c''} for the camera origin while
+// it stages them.)
 //   pl       float4 {nx, ny, nz, d}          one per plane
 //   tri      float4 x3 {v0}, {e1}, {e2}      e1 = v1-v0, e2 = v2-v0 (objects.cs:238-239)
 //   geo      float4 per host primitive: sphere centre or plane/triangle normal
@@ -63,10 +63,6 @@ struct DevScene {
     const float4 *grp_f;      // ns_padded / RT_GROUP bounding balls
     const float4 *sup_f;      // nsup_padded balls (padding: never-pass entries)
     const float4 *chk_f;      // nchk_padded balls
-    const float4 *sph_cam;    // per frame: {p', filter term} for the camera origin
-    const float4 *grp_cam;
-    const float4 *sup_cam;
-    const float4 *chk_cam;
     const int *sph_orig;
     const float4 *pl;
     const int *pl_orig;
@@ -161,8 +157,6 @@ struct DevFrame {
 };
 
 // Launch wrappers (rt_kernels.hip).  All enqueue on `stream` and return at once.
-// Fills the *_cam arrays of the scene (writable views of the same pointers).
-void rtk_setup_camera(const DevScene &s, const DevCamera &cam, hipStream_t stream);
 void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels,
                  int grid_blocks, hipStream_t stream);
 // reflecting: the level's records that need a reflection trace (queue A) or the others (B).

@@ -423,26 +423,15 @@ __device__ __forceinline__ f4raw filter_ray(const FilterOrigin &fo, f3 d)
 }
 
 // ---------------------------------------------------------------------------------------
-// setup_camera: every primary ray starts at camera.position, so the filter's per-entry
-// term -c'' for that origin is computed once per frame for spheres and bounding balls of all
-// three levels: sph_cam[i] = {p', -c''}, grp_cam[g] = {P', -c''_g}, likewise sup_cam, chk_cam
-// (ns_padded >= 64 whenever there is a sphere, and the coarse arrays have at most that many entries).
+// Camera terms: every primary ray starts at camera.position, so the filter's per-entry term
+// -c'' for that origin depends on the entry alone.  The primary kernel forms it while it stages
+// an entry in LDS ({p', W} -> {p', -c''}; 3 FMA and a subtraction per entry and workgroup, far
+// cheaper than a launch of its own per frame) and its loops then take -c'' as given.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float4 camera_term(const float4 pf, const f4raw lane)
 {
     const float chain = __builtin_fmaf(lane.x, pf.x, __builtin_fmaf(lane.y, pf.y, __builtin_fmaf(lane.z, pf.z, pf.w)));
     return make_float4(pf.x, pf.y, pf.z, chain - lane.w);   // padding: -inf, never passes
-}
-
-__global__ void __launch_bounds__(256) k_setup_camera(DevScene s, DevCamera cam)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= s.ns_padded) return;
-    const FilterOrigin fo = filter_origin(s, mk3(cam.pos[0], cam.pos[1], cam.pos[2]));
-    const_cast<float4 *>(s.sph_cam)[i] = camera_term(s.sph_f[i], fo.lane);
-    if (i < s.ns_padded / RT_GROUP) const_cast<float4 *>(s.grp_cam)[i] = camera_term(s.grp_f[i], fo.lane_g);
-    if (i < s.nsup_padded) const_cast<float4 *>(s.sup_cam)[i] = camera_term(s.sup_f[i], fo.lane_s);
-    if (i < s.nchk_padded) const_cast<float4 *>(s.chk_cam)[i] = camera_term(s.chk_f[i], fo.lane_c);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -509,24 +498,41 @@ struct CandidateWalk {
 };
 
 // Filter entries of spheres [base, base + count) and their balls (count: a multiple of RT_SUPER).
-__device__ __forceinline__ void stage_chunk(WalkLds &L, const float4 *sph_src, const float4 *grp_src,
-                                            const float4 *sup_src, int base, int count)
+// CAMERA: entries become camera terms for the origin whose operands are fo's.
+template <bool CAMERA>
+__device__ __forceinline__ void stage_chunk(WalkLds &L, const DevScene &s, const FilterOrigin &fo, int base, int count)
 {
     const float4 never = make_float4(0.f, 0.f, 0.f, -INFINITY);
-    for (int i = threadIdx.x; i < count; i += blockDim.x) L.sph[i] = sph_src[base + i];
+    for (int i = threadIdx.x; i < count; i += blockDim.x)
+        L.sph[i] = CAMERA ? camera_term(s.sph_f[base + i], fo.lane) : s.sph_f[base + i];
     const int ng = count / RT_GROUP;
-    for (int i = threadIdx.x; i < ng; i += blockDim.x) L.grp[i] = grp_src[base / RT_GROUP + i];
+    for (int i = threadIdx.x; i < ng; i += blockDim.x)
+        L.grp[i] = CAMERA ? camera_term(s.grp_f[base / RT_GROUP + i], fo.lane_g) : s.grp_f[base / RT_GROUP + i];
     if (threadIdx.x < FA_LDS_SLACK) L.grp[ng + threadIdx.x] = never;
     // Coarse balls: padded to whole trips (the source array is padded the same way).
     const int ns = count / RT_SUPER;
-    if ((int)threadIdx.x < SUP_LDS_ENTRIES) L.sup[threadIdx.x] = (int)threadIdx.x < ns ? sup_src[base / RT_SUPER + threadIdx.x] : never;
+    if ((int)threadIdx.x < SUP_LDS_ENTRIES) {
+        float4 e = never;
+        if ((int)threadIdx.x < ns) {
+            e = s.sup_f[base / RT_SUPER + threadIdx.x];
+            if (CAMERA) e = camera_term(e, fo.lane_s);
+        }
+        L.sup[threadIdx.x] = e;
+    }
 }
 
 // Balls [first, first + count) of the chunks (count: a multiple of FA_TRIP, at most GRP_CHUNK).
-__device__ __forceinline__ void stage_chunk_balls(WalkLds &L, const float4 *chk_src, int first, int count)
+template <bool CAMERA>
+__device__ __forceinline__ void stage_chunk_balls(WalkLds &L, const DevScene &s, const f4raw lane_c, int first, int count)
 {
-    for (int i = threadIdx.x; i < count + FA_LDS_SLACK; i += blockDim.x)
-        L.grp[i] = i < count ? chk_src[first + i] : make_float4(0.f, 0.f, 0.f, -INFINITY);
+    for (int i = threadIdx.x; i < count + FA_LDS_SLACK; i += blockDim.x) {
+        float4 e = make_float4(0.f, 0.f, 0.f, -INFINITY);
+        if (i < count) {
+            e = s.chk_f[first + i];
+            if (CAMERA) e = camera_term(e, lane_c);
+        }
+        L.grp[i] = e;
+    }
     if (threadIdx.x < GRP_WORDS) L.wg_bits[threadIdx.x] = 0u;
 }
 
@@ -836,15 +842,16 @@ __device__ __forceinline__ void walk_chunk(WalkLds &L, const int cnt, const floa
 // tested GRP_CHUNK at a time with a GROUP loop, and the waves' pass bits are ORed in LDS because
 // staging a chunk is the workgroup's business).  Every thread of the workgroup must call it.
 template <int K, bool TRACE, bool SPLIT, class Visit>
-__device__ __forceinline__ void for_each_chunk(WalkLds &L, const int nsp, const int nchk_padded, const float4 *chk_src,
-                                               const f4raw (&rq)[4], const f4raw lane_c, FilterWork &fw, Visit &&visit)
+__device__ __forceinline__ void for_each_chunk(WalkLds &L, const DevScene &s, const f4raw (&rq)[4], const f4raw lane_c,
+                                               FilterWork &fw, Visit &&visit)
 {
     constexpr bool split = SPLIT && K > 1;
     constexpr int NB = split ? K : 1;
+    const int nsp = s.ns_padded, nchk_padded = s.nchk_padded;
     for (int first = 0; first < nchk_padded; first += GRP_CHUNK) {
         const int n = min(GRP_CHUNK, nchk_padded - first);
         __syncthreads();   // whoever still reads the staged arrays is done
-        stage_chunk_balls(L, chk_src, first, n);
+        stage_chunk_balls<!TRACE>(L, s, lane_c, first, n);
         __syncthreads();
         int i = 0;
         unsigned addr = lds_offset(L.grp), qaddr = lds_offset(L.cand) + 4u * threadIdx.x;
@@ -913,7 +920,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     const f3 o = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
     const FilterOrigin fo = filter_origin(s, o);
     if (!MULTI) {
-        stage_chunk(L, s.sph_cam, s.grp_cam, s.sup_cam, 0, nsp);
+        stage_chunk<true>(L, s, fo, 0, nsp);
         __syncthreads();
     }
     FilterWork fw = {0, 0, 0};
@@ -965,10 +972,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
                 walk_chunk<PRIM_PX, false, false>(L, nsp, s.sph, s.sph_orig, rq, fo.lane_s, fo.lane_g, fo.lane, fw, pc,
                                                   exact);
         } else {
-            for_each_chunk<PRIM_PX, false, false>(L, nsp, s.nchk_padded, s.chk_cam, rq, fo.lane_c, fw,
-                                                  [&](const int base, const int cnt) {
+            for_each_chunk<PRIM_PX, false, false>(L, s, rq, fo.lane_c, fw, [&](const int base, const int cnt) {
                 __syncthreads();
-                stage_chunk(L, s.sph_cam, s.grp_cam, s.sup_cam, base, cnt);
+                stage_chunk<true>(L, s, fo, base, cnt);
                 __syncthreads();
                 walk_chunk<PRIM_PX, false, false>(L, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_s, fo.lane_g,
                                                   fo.lane, fw, pc, exact);
@@ -1090,10 +1096,9 @@ __device__ __forceinline__ void traverse(const DevScene &s, WalkLds &L,
         if (nsp > 0)
             walk_chunk<NR, true, SPLIT>(L, nsp, s.sph, s.sph_orig, rq, fo.lane_s, fo.lane_g, fo.lane, fw, pc, exact);
     } else {
-        for_each_chunk<NR, true, SPLIT>(L, nsp, s.nchk_padded, s.chk_f, rq, fo.lane_c, fw,
-                                        [&](const int base, const int cnt) {
+        for_each_chunk<NR, true, SPLIT>(L, s, rq, fo.lane_c, fw, [&](const int base, const int cnt) {
             __syncthreads();
-            stage_chunk(L, s.sph_f, s.grp_f, s.sup_f, base, cnt);
+            stage_chunk<false>(L, s, fo, base, cnt);
             __syncthreads();
             walk_chunk<NR, true, SPLIT>(L, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_s, fo.lane_g, fo.lane,
                                         fw, pc, exact);
@@ -1294,7 +1299,7 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
     const int n = SEC ? f.cnt[2 * level] : f.cnt[2 * level + 1];
     const int ntiles = (n + 255) >> 8;
     if (!MULTI && (int)blockIdx.x < ntiles) {
-        stage_chunk(L, s.sph_f, s.grp_f, s.sup_f, 0, s.ns_padded);
+        stage_chunk<false>(L, s, FilterOrigin{}, 0, s.ns_padded);
         __syncthreads();
     }
     TestCount tc = {0, 0, 0, 0, 0, 0};
@@ -1448,7 +1453,7 @@ k_trace_levels(DevScene s, DevFrame f)
         const int kind = job[0], lvl = job[1], tile = job[2], n = job[3], walk = job[4];
         if (kind == SCHED_JOB_EXIT) break;
         if (!MULTI && !staged) {
-            stage_chunk(L, s.sph_f, s.grp_f, s.sup_f, 0, s.ns_padded);
+            stage_chunk<false>(L, s, FilterOrigin{}, 0, s.ns_padded);
             staged = true;
         }
         __syncthreads();   // job[] read by all, spheres staged
@@ -1619,12 +1624,6 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
 // ---------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------
-void rtk_setup_camera(const DevScene &s, const DevCamera &cam, hipStream_t stream)
-{
-    if (s.ns_padded <= 0) return;
-    hipLaunchKernelGGL(k_setup_camera, dim3((s.ns_padded + 255) / 256), dim3(256), 0, stream, s, cam);
-}
-
 // Scenes whose spheres fit one LDS chunk use the kernels that stage it once per workgroup.
 static bool multi_chunk(const DevScene &s) { return s.ns_padded > SPH_CHUNK; }
 
