@@ -249,6 +249,20 @@ int rt_render_bands_device(rt_ctx *ctx, const rt_camera *camera, int width, int 
  * RT_ERR_INVALID_ARG. */
 int rt_band_rows(int height, int band_rows, int part, int parts);
 
+/*
+ * Optional post-pass: the anti-aliasing filter the host's present path applies to the frame
+ * AFTER the hand-off (fxaa() in shaders/screen_fxaa_fs.glsl:80-140, called from main()
+ * :426-431 on the uploaded texture), over a width x height frame of 0x00RRGGBB ints in
+ * device memory on the context's first device; input and output must not overlap.  For
+ * hosts that present from device memory or write frames to disk without a GL context; the
+ * unchanged C# host keeps its shader and does not call this.  The sampler is the one
+ * surface.cs:36-38 configures (LINEAR, REPEAT), evaluated in FP32; a GL implementation's own
+ * filter-weight precision makes its output differ from this in the last bits.  Enqueued on
+ * hip_stream (NULL: the context's stream) without synchronising.
+ */
+int rt_fxaa_device(rt_ctx *ctx, const int32_t *dev_pixels_in, int32_t *dev_pixels_out,
+                   int width, int height, void *hip_stream);
+
 /* Counters and timings of the last render call.  Synchronises the context's
  * devices (needed to read the device-side counters). */
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);

@@ -78,6 +78,8 @@ def lib() -> C.CDLL:
         L.orc_render.argtypes = [S, T, C.c_int, Cam, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(orc_counters)]
         L.orc_render.restype = C.c_int
+        L.orc_fxaa.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_fxaa.restype = None
         L.orc_num_threads.argtypes = []
         L.orc_num_threads.restype = C.c_int
         _lib = L
@@ -148,6 +150,14 @@ def texel(hit, tex_w: int, tex_h: int) -> Tuple[int, int]:
 
 def checker_white(hit) -> bool:
     return bool(lib().orc_checker_white(_f3(*map(float, hit))))
+
+
+def fxaa(frame: np.ndarray) -> np.ndarray:
+    """orc_fxaa over an int32 [h, w] frame of 0x00RRGGBB pixels."""
+    src = np.ascontiguousarray(frame, dtype=np.int32)
+    out = np.empty_like(src)
+    lib().orc_fxaa(src.ctypes.data, src.shape[1], src.shape[0], out.ctypes.data)
+    return out
 
 
 def num_threads() -> int:

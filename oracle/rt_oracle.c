@@ -509,3 +509,94 @@ int orc_render(const rt_scene *s, const orc_texture *tex, int ntex, const rt_cam
     if (counters) *counters = total;
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * FXAA, screen_fxaa_fs.glsl:80-140 (see rt_oracle.h).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { float r, g, b; } fx_rgb;
+
+static int fx_wrap(int i, int n)   /* GL_REPEAT */
+{
+    i %= n;
+    return i < 0 ? i + n : i;
+}
+
+static fx_rgb fx_texel(const int32_t *img, int w, int x, int y)
+{
+    const uint32_t p = (uint32_t)img[(size_t)y * (size_t)w + (size_t)x];
+    fx_rgb c;
+    c.r = (float)((p >> 16) & 255u) / 255.0f;
+    c.g = (float)((p >> 8) & 255u) / 255.0f;
+    c.b = (float)(p & 255u) / 255.0f;
+    return c;
+}
+
+static float fx_mix(float a, float b, float t) { return a + (b - a) * t; }
+
+/* texture2D(tex, (u, v)) with GL_LINEAR / GL_REPEAT. */
+static fx_rgb fx_sample(const int32_t *img, int w, int h, float u, float v)
+{
+    const float xs = u * (float)w - 0.5f, ys = v * (float)h - 0.5f;
+    const float xf = floorf(xs), yf = floorf(ys);
+    const float fx = xs - xf, fy = ys - yf;
+    const int x0 = fx_wrap((int)xf, w), x1 = fx_wrap((int)xf + 1, w);
+    const int y0 = fx_wrap((int)yf, h), y1 = fx_wrap((int)yf + 1, h);
+    const fx_rgb t00 = fx_texel(img, w, x0, y0), t10 = fx_texel(img, w, x1, y0);
+    const fx_rgb t01 = fx_texel(img, w, x0, y1), t11 = fx_texel(img, w, x1, y1);
+    fx_rgb c;
+    c.r = fx_mix(fx_mix(t00.r, t10.r, fx), fx_mix(t01.r, t11.r, fx), fy);
+    c.g = fx_mix(fx_mix(t00.g, t10.g, fx), fx_mix(t01.g, t11.g, fx), fy);
+    c.b = fx_mix(fx_mix(t00.b, t10.b, fx), fx_mix(t01.b, t11.b, fx), fy);
+    return c;
+}
+
+static float fx_luma(fx_rgb c) { return (c.r * 0.299f + c.g * 0.587f) + c.b * 0.114f; }   /* dot(rgb, luma) */
+
+static uint32_t fx_byte(float c)
+{
+    if (!(c > 0.0f)) return 0u;
+    if (c > 1.0f) c = 1.0f;
+    return (uint32_t)(c * 255.0f + 0.5f);
+}
+
+void orc_fxaa(const int32_t *in, int w, int h, int32_t *out)
+{
+    const float ivx = 1.0f / (float)w, ivy = 1.0f / (float)h;                    /* :94 */
+    const float reduce_min = 1.0f / 128.0f, reduce_mul = 1.0f / 8.0f, span_max = 8.0f;
+    const float ta = (float)(1.0 / 3.0 - 0.5), tb = (float)(2.0 / 3.0 - 0.5);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            const float fcx = (float)x + 0.5f, fcy = (float)y + 0.5f;           /* uv * resolution, :428 */
+            const fx_rgb nw = fx_sample(in, w, h, (fcx - 1.0f) * ivx, (fcy - 1.0f) * ivy);   /* :95-103 */
+            const fx_rgb ne = fx_sample(in, w, h, (fcx + 1.0f) * ivx, (fcy - 1.0f) * ivy);
+            const fx_rgb sw = fx_sample(in, w, h, (fcx - 1.0f) * ivx, (fcy + 1.0f) * ivy);
+            const fx_rgb se = fx_sample(in, w, h, (fcx + 1.0f) * ivx, (fcy + 1.0f) * ivy);
+            const float mu = fcx * ivx, mv = fcy * ivy;
+            const fx_rgb m = fx_sample(in, w, h, mu, mv);                        /* :104 */
+            const float l_nw = fx_luma(nw), l_ne = fx_luma(ne), l_sw = fx_luma(sw), l_se = fx_luma(se),
+                        l_m = fx_luma(m);                                        /* :106-111 */
+            const float l_min = fminf(l_m, fminf(fminf(l_nw, l_ne), fminf(l_sw, l_se)));   /* :112-113 */
+            const float l_max = fmaxf(l_m, fmaxf(fmaxf(l_nw, l_ne), fmaxf(l_sw, l_se)));
+            float dx = -((l_nw + l_ne) - (l_sw + l_se));                         /* :116-117 */
+            float dy = (l_nw + l_sw) - (l_ne + l_se);
+            const float dir_reduce = fmaxf((((l_nw + l_ne) + l_sw) + l_se) * (0.25f * reduce_mul), reduce_min);
+            const float rcp = 1.0f / (fminf(fabsf(dx), fabsf(dy)) + dir_reduce);  /* :122 */
+            dx = fminf(span_max, fmaxf(-span_max, dx * rcp)) * ivx;              /* :123-125 */
+            dy = fminf(span_max, fmaxf(-span_max, dy * rcp)) * ivy;
+            const fx_rgb a1 = fx_sample(in, w, h, mu + dx * ta, mv + dy * ta);   /* :127-129 */
+            const fx_rgb a2 = fx_sample(in, w, h, mu + dx * tb, mv + dy * tb);
+            const fx_rgb b1 = fx_sample(in, w, h, mu + dx * -0.5f, mv + dy * -0.5f);   /* :130-132 */
+            const fx_rgb b2 = fx_sample(in, w, h, mu + dx * 0.5f, mv + dy * 0.5f);
+            fx_rgb ca, cb;
+            ca.r = 0.5f * (a1.r + a2.r), ca.g = 0.5f * (a1.g + a2.g), ca.b = 0.5f * (a1.b + a2.b);
+            cb.r = ca.r * 0.5f + 0.25f * (b1.r + b2.r);
+            cb.g = ca.g * 0.5f + 0.25f * (b1.g + b2.g);
+            cb.b = ca.b * 0.5f + 0.25f * (b1.b + b2.b);
+            const float l_b = fx_luma(cb);                                       /* :134-138 */
+            const fx_rgb c = (l_b < l_min || l_b > l_max) ? ca : cb;
+            /* alpha: texColor.a, the 0 byte of the 0x00RRGGBB texel */
+            out[(size_t)y * (size_t)w + (size_t)x] = (int32_t)((fx_byte(c.r) << 16) | (fx_byte(c.g) << 8) | fx_byte(c.b));
+        }
+    }
+}

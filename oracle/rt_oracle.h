@@ -92,6 +92,17 @@ int orc_render(const rt_scene *s, const orc_texture *tex, int ntex, const rt_cam
 
 int orc_num_threads(void);
 
+/*
+ * The present path's anti-aliasing filter, /root/reference/shaders/screen_fxaa_fs.glsl:80-140
+ * as main() applies it to the CPU-rendered texture (:426-431), restated over the 0x00RRGGBB
+ * frame: pixel (x, y) is the fragment with uv * resolution = (x + 0.5, y + 0.5); texture2D is
+ * the sampler surface.cs:36-38 sets up (LINEAR filter, the default REPEAT wrap, texel =
+ * byte / 255) evaluated in FP32; the colour goes back to bytes by round-to-nearest.  What a GL
+ * implementation computes differs in the precision of its filter weights and its interpolation of
+ * uv, so this pins the arithmetic of the library's post-pass, not a particular GPU's output.
+ */
+void orc_fxaa(const int32_t *in, int w, int h, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,7 @@ EXPORTS = {
          C.c_void_p, C.c_void_p],
     ),
     "rt_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rt_fxaa_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rt_pin_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "rt_unpin_pixels": (C.c_int, [C.c_void_p]),
     "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(rt_stats)]),

@@ -870,6 +870,22 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, in
     return RT_OK;
 }
 
+int rt_fxaa_device(rt_ctx *ctx, const int32_t *dev_pixels_in, int32_t *dev_pixels_out, int w, int h, void *hip_stream)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (w <= 0 || h <= 0) return fail(ctx, RT_ERR_INVALID_ARG, "bad frame size %d x %d", w, h);
+    if ((long long)w * (long long)h > INT32_MAX) return fail(ctx, RT_ERR_LIMIT, "frame exceeds 2^31-1 pixels");
+    if (!dev_pixels_in || !dev_pixels_out) return fail(ctx, RT_ERR_INVALID_ARG, "a frame pointer is NULL");
+    const size_t n = (size_t)w * (size_t)h;
+    if (dev_pixels_in < dev_pixels_out + n && dev_pixels_out < dev_pixels_in + n)
+        return fail(ctx, RT_ERR_INVALID_ARG, "the filter reads neighbours: input and output frames must not overlap");
+    DeviceState &d = ctx->dev[0];
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    rtk_fxaa(dev_pixels_in, dev_pixels_out, w, h, hip_stream ? static_cast<hipStream_t>(hip_stream) : d.stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
 int rt_unpin_pixels(rt_ctx *ctx)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;

@@ -1622,8 +1622,90 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
 }
 
 // ---------------------------------------------------------------------------------------
+// fxaa: the filter the host's present path applies to the frame after the hand-off
+// (screen_fxaa_fs.glsl:80-140, called from main() :426-431), as an optional post-pass over the
+// 0x00RRGGBB frame in device memory.  Pixel (x, y) is the fragment with uv * resolution =
+// (x + 0.5, y + 0.5); texture2D is the sampler of surface.cs:36-38 (LINEAR, the default REPEAT
+// wrap, texel = byte / 255) evaluated in FP32, operation by operation; colours go back to bytes
+// by round-to-nearest and the alpha byte stays 0 (texColor.a).  Bandwidth-bound: 4 bytes read
+// (neighbours come from cache) and 4 written per pixel.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int fx_wrap(int i, int n)
+{
+    i %= n;
+    return i < 0 ? i + n : i;
+}
+__device__ __forceinline__ f3 fx_texel(const int32_t *img, int w, int x, int y)
+{
+    const uint32_t p = (uint32_t)img[(size_t)y * (size_t)w + (size_t)x];
+    return mk3(ieee_div((float)((p >> 16) & 255u), 255.0f), ieee_div((float)((p >> 8) & 255u), 255.0f),
+               ieee_div((float)(p & 255u), 255.0f));
+}
+__device__ __forceinline__ float fx_mix(float a, float b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ f3 fx_sample(const int32_t *img, int w, int h, float u, float v)
+{
+    const float xs = u * (float)w - 0.5f, ys = v * (float)h - 0.5f;
+    const float xf = floorf(xs), yf = floorf(ys);
+    const float fx = xs - xf, fy = ys - yf;
+    const int x0 = fx_wrap((int)xf, w), x1 = fx_wrap((int)xf + 1, w);
+    const int y0 = fx_wrap((int)yf, h), y1 = fx_wrap((int)yf + 1, h);
+    const f3 t00 = fx_texel(img, w, x0, y0), t10 = fx_texel(img, w, x1, y0);
+    const f3 t01 = fx_texel(img, w, x0, y1), t11 = fx_texel(img, w, x1, y1);
+    return mk3(fx_mix(fx_mix(t00.x, t10.x, fx), fx_mix(t01.x, t11.x, fx), fy),
+               fx_mix(fx_mix(t00.y, t10.y, fx), fx_mix(t01.y, t11.y, fx), fy),
+               fx_mix(fx_mix(t00.z, t10.z, fx), fx_mix(t01.z, t11.z, fx), fy));
+}
+__device__ __forceinline__ float fx_luma(f3 c) { return (c.x * 0.299f + c.y * 0.587f) + c.z * 0.114f; }
+__device__ __forceinline__ uint32_t fx_byte(float c)
+{
+    if (!(c > 0.0f)) return 0u;
+    if (c > 1.0f) c = 1.0f;
+    return (uint32_t)(c * 255.0f + 0.5f);
+}
+
+__global__ void __launch_bounds__(256) k_fxaa(const int32_t *in, int32_t *out, int w, int h)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= w || y >= h) return;
+    const float ivx = ieee_div(1.0f, (float)w), ivy = ieee_div(1.0f, (float)h);   // :94
+    const float reduce_min = 1.0f / 128.0f, reduce_mul = 1.0f / 8.0f, span_max = 8.0f;
+    const float ta = (float)(1.0 / 3.0 - 0.5), tb = (float)(2.0 / 3.0 - 0.5);
+    const float fcx = (float)x + 0.5f, fcy = (float)y + 0.5f;
+    const f3 nw = fx_sample(in, w, h, (fcx - 1.0f) * ivx, (fcy - 1.0f) * ivy);     // :95-103
+    const f3 ne = fx_sample(in, w, h, (fcx + 1.0f) * ivx, (fcy - 1.0f) * ivy);
+    const f3 sw = fx_sample(in, w, h, (fcx - 1.0f) * ivx, (fcy + 1.0f) * ivy);
+    const f3 se = fx_sample(in, w, h, (fcx + 1.0f) * ivx, (fcy + 1.0f) * ivy);
+    const float mu = fcx * ivx, mv = fcy * ivy;
+    const f3 m = fx_sample(in, w, h, mu, mv);                                     // :104
+    const float l_nw = fx_luma(nw), l_ne = fx_luma(ne), l_sw = fx_luma(sw), l_se = fx_luma(se), l_m = fx_luma(m);
+    const float l_min = fminf(l_m, fminf(fminf(l_nw, l_ne), fminf(l_sw, l_se)));  // :112-113
+    const float l_max = fmaxf(l_m, fmaxf(fmaxf(l_nw, l_ne), fmaxf(l_sw, l_se)));
+    float dx = -((l_nw + l_ne) - (l_sw + l_se));                                  // :116-117
+    float dy = (l_nw + l_sw) - (l_ne + l_se);
+    const float dir_reduce = fmaxf((((l_nw + l_ne) + l_sw) + l_se) * (0.25f * reduce_mul), reduce_min);
+    const float rcp = ieee_div(1.0f, fminf(fabsf(dx), fabsf(dy)) + dir_reduce);   // :122
+    dx = fminf(span_max, fmaxf(-span_max, dx * rcp)) * ivx;                       // :123-125
+    dy = fminf(span_max, fmaxf(-span_max, dy * rcp)) * ivy;
+    const f3 a1 = fx_sample(in, w, h, mu + dx * ta, mv + dy * ta);                // :127-129
+    const f3 a2 = fx_sample(in, w, h, mu + dx * tb, mv + dy * tb);
+    const f3 b1 = fx_sample(in, w, h, mu + dx * -0.5f, mv + dy * -0.5f);          // :130-132
+    const f3 b2 = fx_sample(in, w, h, mu + dx * 0.5f, mv + dy * 0.5f);
+    const f3 ca = mk3(0.5f * (a1.x + a2.x), 0.5f * (a1.y + a2.y), 0.5f * (a1.z + a2.z));
+    const f3 cb = mk3(ca.x * 0.5f + 0.25f * (b1.x + b2.x), ca.y * 0.5f + 0.25f * (b1.y + b2.y),
+                      ca.z * 0.5f + 0.25f * (b1.z + b2.z));
+    const float l_b = fx_luma(cb);                                                // :134-138
+    const f3 c = (l_b < l_min || l_b > l_max) ? ca : cb;
+    out[(size_t)y * (size_t)w + (size_t)x] = (int32_t)((fx_byte(c.x) << 16) | (fx_byte(c.y) << 8) | fx_byte(c.z));
+}
+
+// ---------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------
+void rtk_fxaa(const int32_t *in, int32_t *out, int w, int h, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_fxaa, dim3((w + 31) / 32, (h + 7) / 8), dim3(256), 0, stream, in, out, w, h);
+}
+
 // Scenes whose spheres fit one LDS chunk use the kernels that stage it once per workgroup.
 static bool multi_chunk(const DevScene &s) { return s.ns_padded > SPH_CHUNK; }
 

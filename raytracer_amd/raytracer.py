@@ -117,6 +117,11 @@ class RenderContext:
             self._ctx, C.byref(camera.as_struct()), width, height, band_rows, part, parts, max_depth,
             C.c_void_p(dev_ptr), C.c_void_p(stream)))
 
+    def fxaa_device(self, dev_in: int, dev_out: int, width: int, height: int, stream: int = 0) -> None:
+        """rt_fxaa_device: the present path's FXAA filter from one device frame to another."""
+        self._check(self._lib.rt_fxaa_device(self._ctx, C.c_void_p(dev_in), C.c_void_p(dev_out), width, height,
+                                             C.c_void_p(stream)))
+
     def stats(self) -> dict:
         st = abi.rt_stats()
         self._check(self._lib.rt_get_stats(self._ctx, C.byref(st)))

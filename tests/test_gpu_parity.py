@@ -208,6 +208,33 @@ def test_pinned_framebuffer_takes_the_direct_copy(oracle):
     rt.context.close()
 
 
+def test_fxaa_post_pass_matches_the_restatement(ctx, oracle):
+    """rt_fxaa_device against the CPU restatement of screen_fxaa_fs.glsl:80-140, bit for bit,
+    on rendered frames (edges, mirror, checkerboard), ragged sizes and a constant frame."""
+    import torch
+    stream = torch.cuda.Stream()
+    frames = []
+    ctx.set_scene(default_scene().flatten())
+    frames.append(ctx.render(Camera(), 640, 360, 5))
+    frames.append(ctx.render(Camera(position=(-1.0, 0.2, 1.0), direction=(0.6, 0.0, 0.8), fov=70.0), 333, 127, 5))
+    ctx.set_scene(scene_1k().flatten())
+    frames.append(ctx.render(Camera(), 960, 540, 4))
+    frames.append(np.full((9, 5), 0x336699, dtype=np.int32))
+    frames.append(np.random.default_rng(5).integers(0, 1 << 24, size=(64, 1), dtype=np.int32))
+    for img in frames:
+        h, w = img.shape
+        src = torch.from_numpy(img).cuda()
+        dst = torch.full_like(src, -1)
+        ctx.fxaa_device(src.data_ptr(), dst.data_ptr(), w, h, stream.cuda_stream)
+        stream.synchronize()
+        ref = oracle.fxaa(img)
+        assert np.array_equal(dst.cpu().numpy(), ref), (w, h)
+    assert np.array_equal(oracle.fxaa(frames[3]), frames[3])   # nothing to smooth in a constant frame
+    assert (oracle.fxaa(frames[0]) != frames[0]).any()
+    with pytest.raises(RtError):
+        ctx.fxaa_device(src.data_ptr(), src.data_ptr(), w, h, 0)
+
+
 def test_errors_follow_the_convention(ctx):
     fresh = RenderContext()
     with pytest.raises(RtError) as e:

@@ -197,3 +197,25 @@ def test_depth_bound_is_the_reference_literal(oracle, fs):
 def test_render_argument_errors(oracle, fs):
     with pytest.raises(ValueError):
         oracle.render(fs, Camera(), 16, 16, rows=(0, 17))
+
+
+def test_fxaa_known_answers(oracle):
+    """screen_fxaa_fs.glsl:92-140 by hand: a constant frame has no direction to blur along; on a
+    straight edge dir is parallel to the edge ((lumaNW+lumaNE)-(lumaSW+lumaSE) = 0 across a
+    vertical edge), so all four taps stay on the pixel's own side; an isolated bright pixel has
+    dir = 0 and keeps its colour, and its diagonal neighbour samples along the anti-diagonal,
+    away from it.  (Interior pixels only: the sampler wraps at the frame's borders.)"""
+    flat = np.full((12, 16), 0x123456, dtype=np.int32)
+    assert np.array_equal(oracle.fxaa(flat), flat)
+    edge = np.zeros((12, 16), dtype=np.int32)
+    edge[:, 8:] = 0xFFFFFF
+    assert np.array_equal(oracle.fxaa(edge)[2:-2, 2:-2], edge[2:-2, 2:-2])
+    assert np.array_equal(oracle.fxaa(edge.T.copy())[2:-2, 2:-2], edge.T[2:-2, 2:-2])
+    dot = np.zeros((12, 16), dtype=np.int32)
+    dot[6, 8] = 0xFFFFFF
+    out = oracle.fxaa(dot)
+    assert out[6, 8] == 0xFFFFFF and out[5, 7] == 0 and out[7, 9] == 0
+    # a diagonal edge IS smoothed: some interior pixel takes an intermediate grey
+    diag = np.where(np.add.outer(np.arange(16), np.arange(16)) >= 16, 0xFFFFFF, 0).astype(np.int32)
+    grey = oracle.fxaa(diag)[3:-3, 3:-3] & 0xFF
+    assert ((grey > 0) & (grey < 255)).any()
