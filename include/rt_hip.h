@@ -141,6 +141,17 @@ typedef struct rt_stats {
     int32_t  reserved;
 } rt_stats;
 
+/* One ray of the host's top-down debug view (Raytracer.Debug, MyApplication.cs:454-486):
+ * what its loop body computes before it draws. */
+typedef struct rt_debug_ray {
+    float   direction[3];   /* GetRayDirection(x, row, w, h)                     (:461)      */
+    int32_t prim;           /* scene.Intersect: host primitive index, -1 = miss  (:464)      */
+    float   hit[3];         /* isect.hitPoint                                    (:468-470)  */
+    float   t;              /* isect.distance                                                */
+    float   normal[3];      /* isect.prim.GetNormal(hitPoint)                    (:471)      */
+    float   reflected[3];   /* direction - 2 * Dot(direction, normal) * normal   (:472)      */
+} rt_debug_ray;
+
 typedef struct rt_ctx rt_ctx;
 
 /* Library / ABI version (RT_API_VERSION of the build). */
@@ -262,6 +273,18 @@ int rt_band_rows(int height, int band_rows, int part, int parts);
  */
 int rt_fxaa_device(rt_ctx *ctx, const int32_t *dev_pixels_in, int32_t *dev_pixels_out,
                    int width, int height, void *hip_stream);
+
+/*
+ * The rays of the host's debug view: for x = 0, x_step, 2 x_step, ... < width the primary ray
+ * of pixel (x, row) of a width x height frame, its closest hit, the surface normal there and
+ * the mirror direction, written to out[0 .. count) in host memory (count = ceil(width /
+ * x_step) <= max_rays, returned through out_count).  Blocking.  The host keeps drawing the
+ * lines itself (Surface.Line); this replaces the GetRayDirection / scene.Intersect /
+ * GetNormal work of Raytracer.Debug's loop (MyApplication.cs:459-478; the reference uses
+ * row 320 and x_step 10).
+ */
+int rt_debug_rays(rt_ctx *ctx, const rt_camera *camera, int width, int height, int row, int x_step,
+                  int max_rays, rt_debug_ray *out, int *out_count);
 
 /* Counters and timings of the last render call.  Synchronises the context's
  * devices (needed to read the device-side counters). */

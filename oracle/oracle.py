@@ -78,6 +78,8 @@ def lib() -> C.CDLL:
         L.orc_render.argtypes = [S, T, C.c_int, Cam, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(orc_counters)]
         L.orc_render.restype = C.c_int
+        L.orc_debug_ray.argtypes = [S, Cam, C.c_int, C.c_int, C.c_int, C.c_int, _f3, C.POINTER(C.c_float), _f3, _f3, _f3]
+        L.orc_debug_ray.restype = C.c_int
         L.orc_fxaa.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_fxaa.restype = None
         L.orc_num_threads.argtypes = []
@@ -109,6 +111,14 @@ def intersect(fs: FlatScene, o, d) -> Tuple[int, float, np.ndarray]:
     p = lib().orc_intersect(C.byref(fs.as_struct()), _f3(*map(float, o)), _f3(*map(float, d)),
                             C.byref(t), hit)
     return p, np.float32(t.value), np.array(hit[:], dtype=np.float32)
+
+
+def debug_ray(fs: FlatScene, cam: Camera, x: int, y: int, w: int, h: int):
+    """orc_debug_ray: (prim, direction, t, hit, normal, reflected); prim = -1 on a miss."""
+    d, hit, n, r, t = _f3(), _f3(), _f3(), _f3(), C.c_float(0)
+    p = lib().orc_debug_ray(C.byref(fs.as_struct()), C.byref(cam.as_struct()), x, y, w, h, d, C.byref(t), hit, n, r)
+    f = lambda v: np.array(v[:], dtype=np.float32)
+    return p, f(d), np.float32(t.value), f(hit), f(n), f(r)
 
 
 def prim_intersect(fs: FlatScene, prim: int, o, d):

@@ -439,6 +439,24 @@ void orc_texel(const float hit[3], int tex_w, int tex_h, int *tx, int *ty)
 
 int orc_checker_white(const float hit[3]) { return checker_white(v3_load(hit)); }
 
+int orc_debug_ray(const rt_scene *s, const rt_camera *cam, int x, int y, int w, int h, float out_dir[3],
+                  float *out_t, float out_hit[3], float out_normal[3], float out_reflected[3])
+{
+    const v3 d = ray_direction(cam, x, y, w, h);                       /* :461 */
+    store3(out_dir, d);
+    float t = 0.0f;
+    v3 hit = {0, 0, 0};
+    const int p = scene_intersect(NULL, s, v3_load(cam->position), d, &t, &hit);   /* :464 */
+    if (p < 0) return -1;
+    const v3 n = prim_normal(s, p, hit);                               /* :471 */
+    const v3 r = v3_sub(d, v3_scale(n, 2.0f * v3_dot(d, n)));          /* :472 */
+    *out_t = t;
+    store3(out_hit, hit);
+    store3(out_normal, n);
+    store3(out_reflected, r);
+    return p;
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -92,6 +92,11 @@ int orc_render(const rt_scene *s, const orc_texture *tex, int ntex, const rt_cam
 
 int orc_num_threads(void);
 
+/* The loop body of Raytracer.Debug, MyApplication.cs:461-472, for pixel (x, y): ray direction,
+ * closest hit (returns the primitive index or -1), normal there, mirror direction. */
+int orc_debug_ray(const rt_scene *s, const rt_camera *cam, int x, int y, int w, int h, float out_dir[3],
+                  float *out_t, float out_hit[3], float out_normal[3], float out_reflected[3]);
+
 /*
  * The present path's anti-aliasing filter, /root/reference/shaders/screen_fxaa_fs.glsl:80-140
  * as main() applies it to the CPU-rendered texture (:426-431), restated over the 0x00RRGGBB

@@ -88,6 +88,17 @@ class rt_stats(C.Structure):
     ]
 
 
+class rt_debug_ray(C.Structure):
+    _fields_ = [
+        ("direction", C.c_float * 3),
+        ("prim", C.c_int32),
+        ("hit", C.c_float * 3),
+        ("t", C.c_float),
+        ("normal", C.c_float * 3),
+        ("reflected", C.c_float * 3),
+    ]
+
+
 # Every symbol include/rt_hip.h declares: name -> (restype, argtypes).
 EXPORTS = {
     "rt_api_version": (C.c_int, []),
@@ -112,6 +123,8 @@ EXPORTS = {
          C.c_void_p, C.c_void_p],
     ),
     "rt_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rt_debug_rays": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.POINTER(rt_debug_ray), C.POINTER(C.c_int)]),
     "rt_fxaa_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rt_pin_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "rt_unpin_pixels": (C.c_int, [C.c_void_p]),

@@ -870,6 +870,32 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, in
     return RT_OK;
 }
 
+int rt_debug_rays(rt_ctx *ctx, const rt_camera *cam, int w, int h, int row, int x_step, int max_rays,
+                  rt_debug_ray *out, int *out_count)
+{
+    int rc = check_render_args(ctx, cam, w, h, 0);
+    if (rc != RT_OK) return rc;
+    if (x_step <= 0 || !out || !out_count) return fail(ctx, RT_ERR_INVALID_ARG, "bad debug-ray arguments");
+    const int count = (w + x_step - 1) / x_step;
+    if (count > max_rays) return fail(ctx, RT_ERR_LIMIT, "%d rays do not fit the caller's %d entries", count, max_rays);
+    static_assert(sizeof(rt_debug_ray) == 14 * sizeof(float), "rt_debug_ray is 14 packed words");
+    DeviceState &d = ctx->dev[0];
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    float *dev = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&dev, (size_t)count * 16 * sizeof(float)));
+    std::vector<float> host((size_t)count * 16);
+    const DevCamera dc = make_camera(cam, w, h, contiguous_rows(0, h));
+    rtk_debug_rays(d.scene, dc, row, x_step, count, dev, d.stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host.data(), dev, host.size() * sizeof(float), hipMemcpyDeviceToHost, d.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "debug rays failed: %s", hipGetErrorString(e));
+    for (int i = 0; i < count; i++) memcpy(&out[i], &host[(size_t)i * 16], sizeof(rt_debug_ray));
+    *out_count = count;
+    return RT_OK;
+}
+
 int rt_fxaa_device(rt_ctx *ctx, const int32_t *dev_pixels_in, int32_t *dev_pixels_out, int w, int h, void *hip_stream)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;

@@ -168,5 +168,8 @@ int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus);
 void rtk_trace_levels(const DevScene &s, const DevFrame &f, int grid_blocks, hipStream_t stream);
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
                      int grid_blocks, hipStream_t stream);
+// Raytracer.Debug's rays: 16 floats per ray (rt_debug_ray's 14 words, then two of padding).
+void rtk_debug_rays(const DevScene &s, const DevCamera &cam, int row, int x_step, int count, float *out,
+                    hipStream_t stream);
 // The present path's FXAA filter over a w x h frame (in and out must not overlap).
 void rtk_fxaa(const int32_t *in, int32_t *out, int w, int h, hipStream_t stream);

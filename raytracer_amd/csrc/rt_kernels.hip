@@ -1699,8 +1699,66 @@ __global__ void __launch_bounds__(256) k_fxaa(const int32_t *in, int32_t *out, i
 }
 
 // ---------------------------------------------------------------------------------------
+// debug_rays: the loop body of Raytracer.Debug (MyApplication.cs:459-478) for the rays
+// x = 0, x_step, ... of one pixel row: ray direction, Scene.Intersect, GetNormal, mirror
+// direction.  A hundred rays per call: every lane scans the whole scene with the literal
+// Intersect code; no filter, no staging.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_debug_rays(DevScene s, DevCamera cam, int row, int x_step, int count,
+                                                   float *out /* 16 floats per ray */)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const f3 o = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
+    const f3 d = primary_direction(cam, i * x_step, row);
+    const float a = dot3(d, d);
+    Closest c = {RT_FLT_MAX, INT_MAX};
+    for (int j = 0; j < s.ns_padded; j++) {
+        const float4 sp = s.sph[j];
+        const f3 op = sub3(o, xyz(sp));
+        const float cc = dot3(op, op) - sp.w;
+        const float x = dot3(d, op);
+        float t;
+        if (sphere_maybe(x, a * cc) && sphere_root(x, cc, a, t)) closest_offer(c, t, s.sph_orig[j]);
+    }
+    for (int j = 0; j < s.np; j++) {
+        const float4 pl = s.pl[j];
+        const f3 n = xyz(pl);
+        float t;
+        if (plane_t(n, (-dot3(n, o)) - pl.w, d, t)) closest_offer(c, t, s.pl_orig[j]);
+    }
+    for (int j = 0; j < s.nt; j++) {
+        const f3 v0 = xyz(s.tri[3 * j]), e1 = xyz(s.tri[3 * j + 1]), e2 = xyz(s.tri[3 * j + 2]);
+        float t;
+        if (triangle_t(e1, e2, sub3(o, v0), d, t)) closest_offer(c, t, s.tri_orig[j]);
+    }
+    float *r = out + 16 * (size_t)i;
+    r[0] = d.x, r[1] = d.y, r[2] = d.z;
+    const bool hit = c.prim != INT_MAX;
+    r[3] = __int_as_float(hit ? c.prim : -1);
+    f3 p = mk3(0.f, 0.f, 0.f), n = p, m = p;
+    if (hit) {
+        p = add3(o, scale3(d, c.t));
+        const int type = __float_as_int(s.mat[3 * c.prim + 1].w) & RT_MF_TYPE_MASK;
+        n = record_normal(s, c.prim, type, p);
+        m = sub3(d, scale3(n, 2.0f * dot3(d, n)));   // direction - 2 * Dot(direction, normal) * normal
+    }
+    r[4] = p.x, r[5] = p.y, r[6] = p.z;
+    r[7] = hit ? c.t : 0.0f;
+    r[8] = n.x, r[9] = n.y, r[10] = n.z;
+    r[11] = m.x, r[12] = m.y, r[13] = m.z;
+    r[14] = r[15] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------
+void rtk_debug_rays(const DevScene &s, const DevCamera &cam, int row, int x_step, int count, float *out,
+                    hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_debug_rays, dim3((count + 63) / 64), dim3(64), 0, stream, s, cam, row, x_step, count, out);
+}
+
 void rtk_fxaa(const int32_t *in, int32_t *out, int w, int h, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_fxaa, dim3((w + 31) / 32, (h + 7) / 8), dim3(256), 0, stream, in, out, w, h);

@@ -117,6 +117,18 @@ class RenderContext:
             self._ctx, C.byref(camera.as_struct()), width, height, band_rows, part, parts, max_depth,
             C.c_void_p(dev_ptr), C.c_void_p(stream)))
 
+    def debug_rays(self, camera: Camera, width: int, height: int, row: int = 320, x_step: int = 10) -> np.ndarray:
+        """rt_debug_rays as a structured array (direction, prim, hit, t, normal, reflected): the
+        rays Raytracer.Debug draws (MyApplication.cs:459-478: row 320, every 10th pixel)."""
+        n = (width + x_step - 1) // x_step
+        buf = (abi.rt_debug_ray * max(n, 1))()
+        count = C.c_int(0)
+        self._check(self._lib.rt_debug_rays(self._ctx, C.byref(camera.as_struct()), width, height, row, x_step,
+                                            n, buf, C.byref(count)))
+        dt = np.dtype([("direction", np.float32, 3), ("prim", np.int32), ("hit", np.float32, 3), ("t", np.float32),
+                       ("normal", np.float32, 3), ("reflected", np.float32, 3)])
+        return np.frombuffer(buf, dtype=dt, count=count.value).copy()
+
     def fxaa_device(self, dev_in: int, dev_out: int, width: int, height: int, stream: int = 0) -> None:
         """rt_fxaa_device: the present path's FXAA filter from one device frame to another."""
         self._check(self._lib.rt_fxaa_device(self._ctx, C.c_void_p(dev_in), C.c_void_p(dev_out), width, height,

@@ -208,6 +208,32 @@ def test_pinned_framebuffer_takes_the_direct_copy(oracle):
     rt.context.close()
 
 
+def test_debug_rays_match_the_restatement(ctx, oracle):
+    """rt_debug_rays: the rays of Raytracer.Debug (row 320, every 10th pixel of the 1080-wide
+    template window, MyApplication.cs:459-478) and a few other rows / scenes, bit for bit."""
+    for scene, cam, (w, h), row, step in [
+        (default_scene(), Camera(), (1080, 1080), 320, 10),
+        (default_scene(), Camera(position=(-1.0, 0.2, 1.0), direction=(0.6, 0.0, 0.8), fov=70.0), (640, 360), 7, 3),
+        (scene_1k(), Camera(), (480, 270), 135, 1),
+    ]:
+        fs = scene.flatten()
+        ctx.set_scene(fs)
+        rays = ctx.debug_rays(cam, w, h, row, step)
+        assert len(rays) == (w + step - 1) // step
+        for i, r in enumerate(rays):
+            p, d, t, hit, n, refl = oracle.debug_ray(fs, cam, i * step, row, w, h)
+            assert r["prim"] == p, (i, r["prim"], p)
+            assert np.array_equal(r["direction"], d)
+            if p >= 0:
+                assert r["t"] == t and np.array_equal(r["hit"], hit)
+                assert np.array_equal(r["normal"], n) and np.array_equal(r["reflected"], refl)
+    s = Scene()
+    s.Add(Sphere(0.0, 0.0, 3.0, 0.4, Material(1.0)))
+    ctx.set_scene(s.flatten())
+    rays = ctx.debug_rays(Camera(), 100, 100, 50, 10)
+    assert (rays["prim"] == -1).any() and (rays["prim"] == 0).any()
+
+
 def test_fxaa_post_pass_matches_the_restatement(ctx, oracle):
     """rt_fxaa_device against the CPU restatement of screen_fxaa_fs.glsl:80-140, bit for bit,
     on rendered frames (edges, mirror, checkerboard), ragged sizes and a constant frame."""
