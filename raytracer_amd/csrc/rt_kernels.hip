@@ -277,7 +277,7 @@ __device__ __forceinline__ void load_record(const float4 *a, const float4 *b, fl
 // frame appends hundreds of thousands of waves' worth of records.  Every thread of the
 // workgroup must call it (two barriers inside); blk is a __shared__ int[12].
 //   A records (need a reflection trace) fill the level from the front, B records from the back.
-template <int N>
+template <int N, bool THROUGH = true>
 __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &s, int level, int *blk,
                                              const bool (&valid)[N], const int (&prim)[N], const f3 (&hit)[N],
                                              const f3 (&view)[N], const int (&parent)[N])
@@ -320,11 +320,21 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
     for (int k = 0; k < N; k++) {
         if (valid[k]) {
             const int slot = is_a[k] ? (level * f.P + base_a + off[k]) : ((level + 1) * f.P - 1 - (base_b + off[k]));
-            store_record(&f.recA[slot], f4raw{hit[k].x, hit[k].y, hit[k].z, __int_as_float(prim[k])});
-            store_record(&f.recB[slot], f4raw{view[k].x, view[k].y, view[k].z, __int_as_float(parent[k])});
+            // THROUGH: the records are read later in this launch, by other XCDs (device-scope
+            // stores); otherwise by a later launch, which sees plain stores.
+            if (THROUGH) {
+                store_record(&f.recA[slot], f4raw{hit[k].x, hit[k].y, hit[k].z, __int_as_float(prim[k])});
+                store_record(&f.recB[slot], f4raw{view[k].x, view[k].y, view[k].z, __int_as_float(parent[k])});
+            } else {
+                f.recA[slot] = make_float4(hit[k].x, hit[k].y, hit[k].z, __int_as_float(prim[k]));
+                f.recB[slot] = make_float4(view[k].x, view[k].y, view[k].z, __int_as_float(parent[k]));
+            }
             // Several walks OR their lights into the record's occlusion words: start from zero.
             if (walks_of(is_a[k], s.nl, f.first_lights) > 1)
-                for (int w = 0; w < f.mask_words; w++) store_word_through(&f.mask[(size_t)w * (size_t)f.slots + slot], 0u);
+                for (int w = 0; w < f.mask_words; w++) {
+                    if (THROUGH) store_word_through(&f.mask[(size_t)w * (size_t)f.slots + slot], 0u);
+                    else f.mask[(size_t)w * (size_t)f.slots + slot] = 0u;
+                }
         }
     }
     __syncthreads();  // blk may be reused by the caller's next trip
@@ -1009,7 +1019,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
             rec_hit[k] = add3(o, scale3(d[k], c.t));
             if (inside[k] && !hit) pixels[pix] = 0;  // MyApplication.cs:423
         }
-        push_records<PRIM_PX>(f, s, 0, blk, rec_valid, rec_prim, rec_hit, d, rec_parent);
+        push_records<PRIM_PX, false>(f, s, 0, blk, rec_valid, rec_prim, rec_hit, d, rec_parent);
     }
     // Counter words in the order of DevCounters; the filter's counts are the same in every lane.
     const unsigned long long cand_total = (unsigned long long)wave_sum(fw.candidates);
