@@ -232,10 +232,14 @@ void build_filter_arrays(PackedScene &out)
         const double c[3] = {s.x, s.y, s.z};
         entry(c, (double)s.w, &out.sph_f[i]);
     }
-    // Bounding balls of every aligned run of `run` spheres: centre = middle of the members'
-    // extent, rounded the way the filter will see it; radius = max over members of
-    // |centre_i - centre| + r_i against that rounded centre, widened by 1e-6 relative.  The
-    // array is padded with never-pass entries to a multiple of `pad` balls.
+    // Bounding balls of every aligned run of `run` spheres: centre = an approximate centre of the
+    // smallest ball around the members (start in the middle of their extent, then step towards
+    // the member that sticks out farthest with steps of 1/2, 1/3, 1/4 ... of the way: Badoiu and
+    // Clarkson's iteration; ~15 % less r*r than the middle of the extent, and the share of rays
+    // that meet a ball goes with r*r), rounded the way the filter will see it; radius = max
+    // over members of |centre_i - centre| + r_i against that rounded centre, widened by 1e-6
+    // relative, so the ball holds its members whatever the iteration did.  The array is padded
+    // with never-pass entries to a multiple of `pad` balls.
     auto balls = [&](size_t run, size_t pad, std::vector<float4> &dst, double &rmax) {
         const size_t nb = (n + run - 1) / run;
         dst.assign((nb + pad - 1) / pad * pad, never);
@@ -252,7 +256,19 @@ void build_filter_arrays(PackedScene &out)
             }
             if (!any) continue;
             double bc[3];
-            for (int k = 0; k < 3; k++) bc[k] = (double)(float)(0.5 * (blo[k] + bhi[k]) - cen[k]) + cen[k];
+            for (int k = 0; k < 3; k++) bc[k] = 0.5 * (blo[k] + bhi[k]);
+            for (int it = 0; it < 64; it++) {
+                double far = -1.0, fc[3] = {bc[0], bc[1], bc[2]};
+                for (size_t i = i0; i < i1; i++) {
+                    if (out.sph_f[i].w == -INFINITY) continue;
+                    const float4 &s = out.sph[i];
+                    const double dx = s.x - bc[0], dy = s.y - bc[1], dz = s.z - bc[2];
+                    const double dist = std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)s.w);
+                    if (dist > far) far = dist, fc[0] = s.x, fc[1] = s.y, fc[2] = s.z;
+                }
+                for (int k = 0; k < 3; k++) bc[k] += (fc[k] - bc[k]) / (double)(it + 2);
+            }
+            for (int k = 0; k < 3; k++) bc[k] = (double)(float)(bc[k] - cen[k]) + cen[k];
             double rad = 0.0;
             for (size_t i = i0; i < i1; i++) {
                 if (out.sph_f[i].w == -INFINITY) continue;
