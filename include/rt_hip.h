@@ -107,7 +107,10 @@ typedef struct rt_scene {
  *              (objects.cs:83; the reference repeats it once per light)
  * sphere/plane/triangle_tests count the Intersect calls the reference's algorithm makes
  * (an occluded light ray stops at its first occluder in primitive order,
- * MyApplication.cs:373-378), whatever the kernels actually evaluate.
+ * MyApplication.cs:373-378), whatever the kernels actually evaluate; like the times they are
+ * meaningful only for calls made while profiling is enabled (without it a light ray stops at
+ * whichever occluder it meets first, which changes no pixel but leaves "first in primitive
+ * order" unknown).  The ray counts are always exact.
  * Times are milliseconds of the last call, measured with HIP events on the stream the
  * kernels ran on and only while profiling is enabled (rt_set_profiling): kernel_ms spans
  * the whole frame pipeline; primary_ms, trace_ms and shade_ms split it into the primary
@@ -290,8 +293,8 @@ int rt_debug_rays(rt_ctx *ctx, const rt_camera *camera, int width, int height, i
  * devices (needed to read the device-side counters). */
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 
-/* Enable (1) or disable (0) device-side ray/test counters and event timing for
- * later render calls on the context.  Off by default: the counters cost atomics. */
+/* Enable (1) or disable (0) the exact Intersect-call counters and event timing for later
+ * render calls on the context.  Off by default. */
 int rt_set_profiling(rt_ctx *ctx, int enable);
 
 #ifdef __cplusplus

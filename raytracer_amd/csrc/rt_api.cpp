@@ -574,6 +574,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     const int shared_walk = d.scene.nl >= 4 ? 3 : 2;
     d.frame.first_lights = tiles0 >= RT_CHAIN_BOUND_TILES_PER_WORKGROUP * d.resident_blocks ? shared_walk : 0;
     if (first_env) d.frame.first_lights = std::max(0, std::min(atoi(first_env), shared_walk));
+    d.frame.any_hit = ctx->profiling ? 0 : 1;
     const DevFrame &f = d.frame;
     HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, FRAME_CONTROL_BYTES, stream));
     d.timed = ctx->profiling;

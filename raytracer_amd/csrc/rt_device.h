@@ -154,6 +154,7 @@ struct DevFrame {
     int max_depth;
     int mask_words;        // ceil(nl / 32), at least 1
     int first_lights;      // lights traced in the same walk as a record's reflection ray (rt_kernels.hip, walks_of)
+    int any_hit;           // 1: a light ray may stop at ANY occluder (the Intersect-call counters are not wanted)
 };
 
 // Launch wrappers (rt_kernels.hip).  All enqueue on `stream` and return at once.

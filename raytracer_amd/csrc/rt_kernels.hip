@@ -736,9 +736,13 @@ __device__ __forceinline__ int run_selected(WalkLds &L, const float4 *sph, const
 // The wave-wide pass bits of the first `ntrips` trips a GROUP loop left in the queue slots
 // (bit 8t + b of word w = entry 8(4w + t) + 7 - b of the array the loop walked), one bitmap
 // per ray when the loop kept the rays apart (NB = K), else one for all (NB = 1).
+// live[k] = 0 takes ray k of this lane out of the vote (its answer is already known), ~0 keeps it.
 template <int NB, int NW>
-__device__ __forceinline__ void gather_pass_bits(const int *cand, const int ntrips, unsigned (&words)[NB][NW])
+__device__ __forceinline__ void gather_pass_bits(const int *cand, const int ntrips, unsigned (&words)[NB][NW],
+                                                 const unsigned (&live)[4])
 {
+    // One mask for all rays (NB = 1): the lane votes while any of its rays is live.
+    const unsigned all = live[0] | live[1] | live[2] | live[3];
 #pragma unroll
     for (int wd = 0; wd < NW; wd++) {
         unsigned bits[NB];
@@ -754,7 +758,7 @@ __device__ __forceinline__ void gather_pass_bits(const int *cand, const int ntri
             }
         }
 #pragma unroll
-        for (int k = 0; k < NB; k++) words[k][wd] = wave_or(bits[k]);
+        for (int k = 0; k < NB; k++) words[k][wd] = wave_or(bits[k] & (NB == 1 ? all : live[k]));
     }
 }
 
@@ -778,7 +782,8 @@ __device__ __forceinline__ void gather_pass_bits(const int *cand, const int ntri
 template <int K, bool TRACE, bool SPLIT, class Exact>
 __device__ __forceinline__ void walk_chunk(WalkLds &L, const int cnt, const float4 *sph, const int *orig,
                                            const f4raw (&rq)[4], const f4raw lane_s, const f4raw lane_g,
-                                           const f4raw lane, FilterWork &fw, PhaseClock &pc, Exact &&exact)
+                                           const f4raw lane, FilterWork &fw, PhaseClock &pc, Exact &&exact,
+                                           const unsigned (&live)[4])
 {
     static_assert(TRACE || !SPLIT, "primary rays use the combined loops");
     constexpr bool split = SPLIT && K > 1;
@@ -796,7 +801,7 @@ __device__ __forceinline__ void walk_chunk(WalkLds &L, const int cnt, const floa
         fw.terms += TRACE ? nsup : 0;
         fw.ray_tests += nsup * K;
         unsigned any[NB][1];
-        gather_pass_bits<NB, 1>(L.cand, nsup / FA_TRIP, any);
+        gather_pass_bits<NB, 1>(L.cand, nsup / FA_TRIP, any, live);
         runs = 0u;
 #pragma unroll
         for (int k = 0; k < NB; k++) runs |= any[k][0];   // bit 8t + 7 - m = run 8t + m
@@ -814,7 +819,7 @@ __device__ __forceinline__ void walk_chunk(WalkLds &L, const int cnt, const floa
     PHASE_MARK(pc, 2)
     static_assert(GRP_WORDS == 4, "the bitmap of a chunk is two 64-bit halves");
     unsigned words[NB][GRP_WORDS];
-    gather_pass_bits<NB, GRP_WORDS>(L.cand, ntrips, words);
+    gather_pass_bits<NB, GRP_WORDS>(L.cand, ntrips, words, live);
     PHASE_MARK(pc, 3)
     // Level 3.
     if constexpr (!split) {
@@ -853,7 +858,7 @@ __device__ __forceinline__ void walk_chunk(WalkLds &L, const int cnt, const floa
 // staging a chunk is the workgroup's business).  Every thread of the workgroup must call it.
 template <int K, bool TRACE, bool SPLIT, class Visit>
 __device__ __forceinline__ void for_each_chunk(WalkLds &L, const DevScene &s, const f4raw (&rq)[4], const f4raw lane_c,
-                                               FilterWork &fw, Visit &&visit)
+                                               FilterWork &fw, const unsigned (&live)[4], Visit &&visit)
 {
     constexpr bool split = SPLIT && K > 1;
     constexpr int NB = split ? K : 1;
@@ -869,7 +874,7 @@ __device__ __forceinline__ void for_each_chunk(WalkLds &L, const DevScene &s, co
         fw.terms += TRACE ? n : 0;
         fw.ray_tests += n * K;
         unsigned words[NB][GRP_WORDS];
-        gather_pass_bits<NB, GRP_WORDS>(L.cand, n / FA_TRIP, words);
+        gather_pass_bits<NB, GRP_WORDS>(L.cand, n / FA_TRIP, words, live);
         if ((threadIdx.x & 63) == 0) {
 #pragma unroll
             for (int wd = 0; wd < GRP_WORDS; wd++) {
@@ -935,6 +940,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     }
     FilterWork fw = {0, 0, 0};
     PhaseClock pc = {};
+    const unsigned all_live[4] = {~0u, ~0u, ~0u, ~0u};
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = tile / tiles_x;
         const int x0 = tx * 32 + (wave & 1) * 16 + (lane & 7) * 2;
@@ -980,14 +986,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
         if constexpr (!MULTI) {
             if (nsp > 0)
                 walk_chunk<PRIM_PX, false, false>(L, nsp, s.sph, s.sph_orig, rq, fo.lane_s, fo.lane_g, fo.lane, fw, pc,
-                                                  exact);
+                                                  exact, all_live);
         } else {
-            for_each_chunk<PRIM_PX, false, false>(L, s, rq, fo.lane_c, fw, [&](const int base, const int cnt) {
+            for_each_chunk<PRIM_PX, false, false>(L, s, rq, fo.lane_c, fw, all_live, [&](const int base, const int cnt) {
                 __syncthreads();
                 stage_chunk<true>(L, s, fo, base, cnt);
                 __syncthreads();
                 walk_chunk<PRIM_PX, false, false>(L, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_s, fo.lane_g,
-                                                  fo.lane, fw, pc, exact);
+                                                  fo.lane, fw, pc, exact, all_live);
             });
         }
         bool rec_valid[PRIM_PX];
@@ -1058,7 +1064,8 @@ struct Rays {
 
 template <int LC, bool SEC, bool SPLIT, bool MULTI>
 __device__ __forceinline__ void traverse(const DevScene &s, WalkLds &L,
-                                         const f3 o, Rays<LC, SEC> &r, TestCount &tc, PhaseClock &pc)
+                                         const f3 o, Rays<LC, SEC> &r, TestCount &tc, PhaseClock &pc,
+                                         const bool any_hit)
 {
     constexpr int NR = LC + (SEC ? 1 : 0);
     static_assert(NR >= 1 && NR <= 4, "one GROUP loop per ray count 1..4");
@@ -1102,16 +1109,25 @@ __device__ __forceinline__ void traverse(const DevScene &s, WalkLds &L,
                 r.sh_first[l] = min(r.sh_first[l], orig);
         }
     };
+    unsigned live[4] = {~0u, ~0u, ~0u, ~0u};
     if constexpr (!MULTI) {   // the scene's spheres are one chunk, staged once per workgroup
         if (nsp > 0)
-            walk_chunk<NR, true, SPLIT>(L, nsp, s.sph, s.sph_orig, rq, fo.lane_s, fo.lane_g, fo.lane, fw, pc, exact);
+            walk_chunk<NR, true, SPLIT>(L, nsp, s.sph, s.sph_orig, rq, fo.lane_s, fo.lane_g, fo.lane, fw, pc, exact, live);
     } else {
-        for_each_chunk<NR, true, SPLIT>(L, s, rq, fo.lane_c, fw, [&](const int base, const int cnt) {
+        for_each_chunk<NR, true, SPLIT>(L, s, rq, fo.lane_c, fw, live, [&](const int base, const int cnt) {
             __syncthreads();
             stage_chunk<false>(L, s, fo, base, cnt);
             __syncthreads();
+            // A light ray that has met an occluder needs no further look at the scene unless the
+            // caller wants the reference's Intersect-call counts, which depend on WHICH occluder
+            // comes first in host order: its lane stops voting for groups on that ray's behalf.
+            if (any_hit) {
+#pragma unroll
+                for (int l = 0; l < LC; l++)
+                    if (r.sh_first[l] != INT_MAX) live[l] = 0u;
+            }
             walk_chunk<NR, true, SPLIT>(L, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_s, fo.lane_g, fo.lane,
-                                        fw, pc, exact);
+                                        fw, pc, exact, live);
         });
     }
     tc.exact += fw.candidates;
@@ -1169,7 +1185,8 @@ __device__ __forceinline__ f3 record_normal(const DevScene &s, int prim, int typ
 template <int LC, bool SEC, bool SPLIT, bool MULTI>
 __device__ __forceinline__ void trace_chunk(const DevScene &s, WalkLds &L, const f3 hit,
                                             const f3 view, const f3 normal, int l0, uint32_t &mask_word,
-                                            Closest &sec_out, f3 &sec_dir, TestCount &tc, PhaseClock &pc)
+                                            Closest &sec_out, f3 &sec_dir, TestCount &tc, PhaseClock &pc,
+                                            const bool any_hit)
 {
     Rays<LC, SEC> r;
 #pragma unroll
@@ -1188,7 +1205,7 @@ __device__ __forceinline__ void trace_chunk(const DevScene &s, WalkLds &L, const
         r.sec.t = RT_FLT_MAX;
         r.sec.prim = INT_MAX;
     }
-    traverse<LC, SEC, SPLIT, MULTI>(s, L, hit, r, tc, pc);
+    traverse<LC, SEC, SPLIT, MULTI>(s, L, hit, r, tc, pc, any_hit);
     PHASE_MARK(pc, 6)
 #pragma unroll
     for (int l = 0; l < LC; l++) {
@@ -1239,7 +1256,7 @@ __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f,
     const bool with_sec = SEC && walk == 0;
     int l0, count;
     walk_lights(SEC, walk, nl, f.first_lights, l0, count);
-#define RT_WALK(LC_, SEC_) trace_chunk<LC_, SEC_, (LCMAX >= 4), MULTI>(s, L, hit, view, normal, l0, word, sec, sec_dir, ltc, pc)
+#define RT_WALK(LC_, SEC_) trace_chunk<LC_, SEC_, (LCMAX >= 4), MULTI>(s, L, hit, view, normal, l0, word, sec, sec_dir, ltc, pc, f.any_hit != 0)
     bool done = false;
     if constexpr (LCMAX >= 4) {
         if (count == 4) {   // never with the reflection ray: a walk has at most four rays

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def ctx():
     c = RenderContext()
+    c.set_profiling(True)   # the Intersect-call counters are compared with the restatement's
     yield c
     c.close()
 
@@ -343,12 +344,33 @@ def test_chunked_scenes(ctx, oracle, nspheres, nl, depth, size):
         assert st[k] == cnt[k], k
 
 
+@pytest.mark.parametrize("nspheres,nl,depth,size", [(3000, 16, 3, (96, 54)), (1500, 2, 3, (160, 90)),
+                                                    (70000, 5, 2, (48, 27))])
+def test_light_rays_may_stop_at_any_occluder(oracle, nspheres, nl, depth, size):
+    """Without profiling a light ray of a multi-chunk scene stops looking once it has met an
+    occluder: the pixels must not notice."""
+    s = synthetic_scene(nspheres, radius=(0.01, 0.06), seed=41 + nspheres)
+    s.lights.clear()
+    for i in range(nl):
+        s.Add(Light(-3.0 + 0.4 * i, -1.0 - 0.05 * i, 0.5 + 0.17 * i))
+    fs, cam, (w, h) = s.flatten(), Camera(), size
+    ref, _ = oracle.render(fs, cam, w, h, max_depth=depth)
+    with RenderContext() as c:
+        c.set_scene(fs)
+        quick = c.render(cam, w, h, depth)          # profiling off: any occluder will do
+        c.set_profiling(True)
+        counted = c.render(cam, w, h, depth)
+    assert_parity(quick, ref, "any-hit light rays")
+    assert np.array_equal(quick, counted)
+
+
 def test_two_device_states_split_rows_and_gather(oracle):
     """rt_create with two device entries (the same GPU twice on a one-GPU box): the frame is
     split into two row blocks, the second is gathered into the first device's frame."""
     fs = default_scene().flatten()
     cam = Camera()
     with RenderContext([0, 0]) as two:
+        two.set_profiling(True)
         two.set_scene(fs)
         for (w, h) in [(200, 150), (64, 33)]:
             gpu = two.render(cam, w, h, 5)
