@@ -483,6 +483,9 @@ struct WalkLds {
     float4 sup[SUP_LDS_ENTRIES];
     int cand[QUEUE_INTS];
     unsigned wg_bits[GRP_WORDS];   // chunks some wave of the workgroup has to walk
+    float ref[4];                  // ... seen from here (thread 0's ray origin),
+    float key[GRP_CHUNK];          // ... their distances from it
+    int order[GRP_CHUNK];          // ... and the order they are walked in, nearest first
 };
 
 // Walks a thread's queued words: next() returns the next sphere index (local to the staged
@@ -858,7 +861,7 @@ __device__ __forceinline__ void walk_chunk(WalkLds &L, const int cnt, const floa
 // staging a chunk is the workgroup's business).  Every thread of the workgroup must call it.
 template <int K, bool TRACE, bool SPLIT, class Visit>
 __device__ __forceinline__ void for_each_chunk(WalkLds &L, const DevScene &s, const f4raw (&rq)[4], const f4raw lane_c,
-                                               FilterWork &fw, const unsigned (&live)[4], Visit &&visit)
+                                               const f3 oc, FilterWork &fw, const unsigned (&live)[4], Visit &&visit)
 {
     constexpr bool split = SPLIT && K > 1;
     constexpr int NB = split ? K : 1;
@@ -884,17 +887,44 @@ __device__ __forceinline__ void for_each_chunk(WalkLds &L, const DevScene &s, co
                 if (all) atomicOr(&L.wg_bits[wd], all);
             }
         }
+        if (threadIdx.x == 0) L.ref[0] = oc.x, L.ref[1] = oc.y, L.ref[2] = oc.z;
         __syncthreads();
-        unsigned chunks[GRP_WORDS];
-#pragma unroll
-        for (int wd = 0; wd < GRP_WORDS; wd++) chunks[wd] = L.wg_bits[wd];
-#pragma clang loop unroll(disable)
-        for (int c = 0; c < n; c++) {
+        // The chunks to walk, nearest first (the rays of a tile start close together): a light
+        // ray that meets an occluder early stops voting early (`live`), and the order cannot
+        // change a result.  Thread c ranks chunk c among the selected ones by the distance of its
+        // ball's centre from thread 0's origin.
+        const int c = threadIdx.x;
+        bool selected = false;
+        float key = INFINITY;
+        if (c < n) {
             // bit 8t + 7 - m of word w = entry 8(4w + t) + m
-            const unsigned word = c < 32 ? chunks[0] : (c < 64 ? chunks[1] : (c < 96 ? chunks[2] : chunks[3]));
-            if (!((word >> (((c & 31) & ~7) + 7 - (c & 7))) & 1u)) continue;
-            const int base = (first + c) * SPH_CHUNK;
-            if (base < nsp) visit(base, min(SPH_CHUNK, nsp - base));
+            selected = (L.wg_bits[c >> 5] >> (((c & 31) & ~7) + 7 - (c & 7))) & 1u;
+            selected = selected && (first + c) * SPH_CHUNK < nsp;
+            const float4 e = L.grp[c];
+            const float dx = e.x - L.ref[0], dy = e.y - L.ref[1], dz = e.z - L.ref[2];
+            if (selected) key = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            if (key != key) key = 0.0f;   // an unrepresentable ball passes always: walk it first
+            L.key[c] = key;
+        }
+        __syncthreads();
+        if (selected) {
+            int rank = 0;
+            for (int u = 0; u < n; u++) {
+                const float ku = L.key[u];
+                rank += (ku < key || (ku == key && u < c)) ? 1 : 0;
+            }
+            L.order[rank] = c;
+        }
+        int count = 0;
+#pragma unroll
+        for (int wd = 0; wd < GRP_WORDS; wd++) count += __popc(__builtin_amdgcn_readfirstlane((int)L.wg_bits[wd]));
+        __syncthreads();
+        // (selected chunks beyond the last sphere do not exist: only padding entries of the ball
+        // array, which never pass, lie there, so `count` is the number of ranks handed out.)
+#pragma clang loop unroll(disable)
+        for (int i = 0; i < count; i++) {
+            const int base = (first + __builtin_amdgcn_readfirstlane(L.order[i])) * SPH_CHUNK;   // workgroup-uniform
+            visit(base, min(SPH_CHUNK, nsp - base));
         }
     }
 }
@@ -988,7 +1018,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
                 walk_chunk<PRIM_PX, false, false>(L, nsp, s.sph, s.sph_orig, rq, fo.lane_s, fo.lane_g, fo.lane, fw, pc,
                                                   exact, all_live);
         } else {
-            for_each_chunk<PRIM_PX, false, false>(L, s, rq, fo.lane_c, fw, all_live, [&](const int base, const int cnt) {
+            for_each_chunk<PRIM_PX, false, false>(L, s, rq, fo.lane_c, fo.oc, fw, all_live,
+                                                  [&](const int base, const int cnt) {
                 __syncthreads();
                 stage_chunk<true>(L, s, fo, base, cnt);
                 __syncthreads();
@@ -1114,7 +1145,7 @@ __device__ __forceinline__ void traverse(const DevScene &s, WalkLds &L,
         if (nsp > 0)
             walk_chunk<NR, true, SPLIT>(L, nsp, s.sph, s.sph_orig, rq, fo.lane_s, fo.lane_g, fo.lane, fw, pc, exact, live);
     } else {
-        for_each_chunk<NR, true, SPLIT>(L, s, rq, fo.lane_c, fw, live, [&](const int base, const int cnt) {
+        for_each_chunk<NR, true, SPLIT>(L, s, rq, fo.lane_c, fo.oc, fw, live, [&](const int base, const int cnt) {
             __syncthreads();
             stage_chunk<false>(L, s, fo, base, cnt);
             __syncthreads();
