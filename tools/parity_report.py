@@ -68,6 +68,11 @@ def main() -> None:
             else:
                 gpu = ctx.render(cam, w, h, depth)
                 st = ctx.stats()
+                # the same frame the way the host renders it (no counters: light rays of
+                # multi-chunk scenes stop at any occluder) must be the same frame
+                ctx.set_profiling(False)
+                unprofiled_same = bool(np.array_equal(ctx.render(cam, w, h, depth), gpu))
+                ctx.set_profiling(True)
             t0 = time.perf_counter()
             ref, cnt = O.render(flat, cam, w, h, max_depth=depth)
             cpu_s = time.perf_counter() - t0
@@ -85,6 +90,7 @@ def main() -> None:
                         "plane_tests", "triangle_tests")
                 entry["counters_agree"] = all(int(st[k]) == int(cnt[k]) for k in keys)
                 entry["rays"] = int(st["rays_primary"] + st["rays_shadow"] + st["rays_secondary"])
+                entry["identical_without_profiling"] = unprofiled_same
             write_pgm(os.path.join(args.out, entry["mismatch_map"]), d)
             report.append(entry)
             print(json.dumps(entry), flush=True)
