@@ -1417,7 +1417,7 @@ struct Taker {
 };
 
 template <int LCMAX, bool MULTI>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 k_trace_levels(DevScene s, DevFrame f)
 {
     __shared__ WalkLds L;
