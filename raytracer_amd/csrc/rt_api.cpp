@@ -7,6 +7,9 @@
 #include "rt_device.h"
 
 #include <algorithm>
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>   // SSE2 streaming stores (baseline x86-64), host pass only
+#endif
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -25,6 +28,19 @@ constexpr int RT_CHAIN_BOUND_TILES_PER_WORKGROUP = 8;
 // Counter slots + level schedule + two record counts per level (DevFrame::counters, sched, cnt).
 constexpr size_t FRAME_CONTROL_BYTES =
     RT_COUNTER_SLOTS * sizeof(DevCounters) + sizeof(DevSched) + 2 * RT_DEV_MAX_LEVELS * sizeof(int);
+
+// Level schedule + record counts: the part of the control block a render call leaves its
+// outcome in (has the schedule stalled, how many records did each level hold).
+constexpr size_t FRAME_OUTCOME_BYTES = sizeof(DevSched) + 2 * RT_DEV_MAX_LEVELS * sizeof(int);
+
+// rt_render on one device renders a large frame as up to RT_MAX_FRAME_PARTS row blocks one after
+// the other, so that the copy of a finished block to the host runs while the next one renders.
+// Small blocks cost more in rendering (the chain of levels does not shrink with the block) than
+// their copy hides: measured on MI355X, two blocks pay from ~3 M pixels (2560x1440: 1.45 -> 1.30
+// ms; 1920x1080: 0.86 -> 1.02 ms), and beyond that blocks of ~4 M pixels are best (3840x2160:
+// two blocks 2.40 ms, four 2.52; 7680x4320: eight blocks 7.7 ms against 10.6 in one piece).
+constexpr int RT_MAX_FRAME_PARTS = 8;
+constexpr long long RT_MIN_SPLIT_PIXELS = 3000000, RT_PART_PIXELS = 4000000;
 
 thread_local std::string g_create_error;
 
@@ -49,9 +65,18 @@ struct DeviceState {
     // last call
     int last_P = 0, last_depth = 0;
     bool timed = false;
+    // Frames rendered in parts: the outcome block of every part, copied to page-locked host
+    // memory behind the part's kernels (snap_parts of them are valid; 0 = the frame was one call
+    // and its outcome is still in device memory).
+    char *outcome_snap = nullptr;
+    int snap_parts = 0;
 };
 
 }  // namespace
+
+// Pixels per chunk of rt_render's staged device-to-host copy (2 MiB: a chunk's DMA takes ~40 us,
+// long enough to amortise its launch, short enough that the last chunk's host copy is brief).
+#define RT_STAGED_COPY_CHUNK_PIXELS ((size_t)512 * 1024)
 
 struct rt_ctx {
     std::vector<DeviceState> dev;
@@ -63,6 +88,9 @@ struct rt_ctx {
     uint32_t textures_loaded = 0;  // bit i: slot i holds an image
     int32_t *staging = nullptr;    // pinned host staging for rt_render
     size_t cap_staging = 0;
+    std::vector<hipEvent_t> copy_ev;   // one per chunk of the framebuffer copy to the host (device 0)
+    hipStream_t copy_stream = nullptr; // carries those copies while device 0's stream renders the next part
+    hipEvent_t part_ev[RT_MAX_FRAME_PARTS] = {};
     int32_t *pinned = nullptr;     // the host's own framebuffer, page-locked by rt_pin_pixels
     void *pinned_base = nullptr;   // start of the registered pages
     size_t pinned_count = 0;
@@ -85,6 +113,35 @@ int fail(rt_ctx *ctx, int code, const char *fmt, ...)
     else g_create_error = buf;
     return code;
 }
+
+// memcpy with streaming stores: the destination (the caller's framebuffer) is written once and
+// not read here, so its lines need not be fetched into the cache first — a third less memory
+// traffic than a chunk-sized memcpy, which uses ordinary stores below the C library's own
+// streaming threshold.  The caller issues the store fence.
+#if defined(__HIP_DEVICE_COMPILE__)   // this file is also parsed for the device, which has no such intrinsics
+void copy_streaming(void *, const void *, size_t) {}
+void store_fence() {}
+#else
+void copy_streaming(void *dst_v, const void *src_v, size_t bytes)
+{
+    char *dst = (char *)dst_v;
+    const char *src = (const char *)src_v;
+    const size_t head = std::min(bytes, (size_t)(-(uintptr_t)dst & 15u));
+    memcpy(dst, src, head);
+    dst += head, src += head, bytes -= head;
+    size_t i = 0;
+    for (; i + 64 <= bytes; i += 64) {
+        const __m128i a = _mm_loadu_si128((const __m128i *)(src + i)), b = _mm_loadu_si128((const __m128i *)(src + i + 16)),
+                      c = _mm_loadu_si128((const __m128i *)(src + i + 32)), d = _mm_loadu_si128((const __m128i *)(src + i + 48));
+        _mm_stream_si128((__m128i *)(dst + i), a);
+        _mm_stream_si128((__m128i *)(dst + i + 16), b);
+        _mm_stream_si128((__m128i *)(dst + i + 32), c);
+        _mm_stream_si128((__m128i *)(dst + i + 48), d);
+    }
+    memcpy(dst + i, src + i, bytes - i);
+}
+void store_fence() { _mm_sfence(); }
+#endif
 
 #define HIP_TRY(ctx, expr)                                                                  \
     do {                                                                                    \
@@ -533,6 +590,15 @@ int check_schedule(rt_ctx *ctx, DeviceState &d)
     static_assert(RT_DEV_MAX_LEVELS >= RT_MAX_DEPTH + 2, "DevSched holds one entry per level");
     if (!d.frame.sched) return RT_OK;
     DevSched sc;
+    if (d.snap_parts > 0) {   // rendered in parts: every part left its outcome in host memory
+        for (int p = 0; p < d.snap_parts; p++) {
+            memcpy(&sc, d.outcome_snap + (size_t)p * FRAME_OUTCOME_BYTES, sizeof sc);
+            if (sc.error)
+                return fail(ctx, RT_ERR_HIP, "device %d: the level schedule stalled at level %d in part %d of the frame; "
+                            "the frame is incomplete", d.device, sc.open_level, p);
+        }
+        return RT_OK;
+    }
     HIP_TRY(ctx, hipMemcpy(&sc, d.frame.sched, sizeof sc, hipMemcpyDeviceToHost));
     static const bool trace = getenv("RT_HIP_SCHED_TRACE") != nullptr;
     if (trace) {
@@ -551,16 +617,22 @@ int check_schedule(rt_ctx *ctx, DeviceState &d)
 }
 
 // Enqueue the whole frame pipeline for the rows of rs on device state d.
+// part < 0: the call is a frame of its own.  part >= 0: part `part` of a frame rendered in parts —
+// the work counters run on from the earlier parts and the part's outcome is copied to
+// d.outcome_snap behind its kernels.
 int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h, const RowSet &rs,
-                 int max_depth, int32_t *dev_pixels, hipStream_t stream)
+                 int max_depth, int32_t *dev_pixels, hipStream_t stream, int part = -1)
 {
     const long long P64 = (long long)rs.rows * (long long)w;
     if (P64 > INT32_MAX) return fail(ctx, RT_ERR_LIMIT, "row block of %lld pixels exceeds 2^31-1", P64);
     const int P = (int)P64;
-    d.last_P = P;
+    d.last_P = part > 0 ? d.last_P + P : P;
     d.last_depth = max_depth;
-    if (P == 0) return RT_OK;
+    d.snap_parts = part < 0 ? 0 : part + 1;
+    if (P == 0) return RT_OK;   // (a frame rendered in parts has no empty part)
     HIP_TRY(ctx, hipSetDevice(d.device));
+    if (part >= 0 && !d.outcome_snap)
+        HIP_TRY(ctx, hipHostMalloc((void **)&d.outcome_snap, RT_MAX_FRAME_PARTS * FRAME_OUTCOME_BYTES, hipHostMallocDefault));
     int rc = ensure_frame(ctx, d, P, max_depth, d.scene.nl);
     if (rc != RT_OK) return rc;
     const DevCamera dc = make_camera(cam, w, h, rs);
@@ -576,7 +648,8 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     if (first_env) d.frame.first_lights = std::max(0, std::min(atoi(first_env), shared_walk));
     d.frame.any_hit = ctx->profiling ? 0 : 1;
     const DevFrame &f = d.frame;
-    HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, FRAME_CONTROL_BYTES, stream));
+    if (part > 0) HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, FRAME_OUTCOME_BYTES, stream));
+    else HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, FRAME_CONTROL_BYTES, stream));
     d.timed = ctx->profiling;
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
     const int blocks = std::max(1, std::min({(P + 255) / 256, d.num_cus * 8, RT_COUNTER_SLOTS}));
@@ -597,6 +670,9 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[2], stream));
     for (int k = max_depth; k >= 0; k--) rtk_shade_level(d.scene, f, k, dev_pixels, blocks, stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[3], stream));
+    if (part >= 0)
+        HIP_TRY(ctx, hipMemcpyAsync(d.outcome_snap + (size_t)part * FRAME_OUTCOME_BYTES, f.sched, FRAME_OUTCOME_BYTES,
+                                    hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -679,8 +755,14 @@ void rt_destroy(rt_ctx *ctx)
         for (int k = 0; k < 5; k++)
             if (d.ev[k]) (void)hipEventDestroy(d.ev[k]);
         if (d.stream) (void)hipStreamDestroy(d.stream);
+        if (d.outcome_snap) (void)hipHostFree(d.outcome_snap);
     }
     if (ctx->staging) (void)hipHostFree(ctx->staging);
+    if (!ctx->dev.empty()) (void)hipSetDevice(ctx->dev[0].device);
+    for (hipEvent_t e : ctx->copy_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->part_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->pinned) (void)hipHostUnregister(ctx->pinned_base);
     delete ctx;
 }
@@ -833,6 +915,74 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, in
         HIP_TRY(ctx, hipHostMalloc((void **)&ctx->staging, (size_t)total * sizeof(int32_t), hipHostMallocDefault));
         ctx->cap_staging = (size_t)total;
     }
+    // The copy to the host: straight into the caller's array when it is page-locked
+    // (rt_pin_pixels), else into pinned staging and from there into the caller's (pageable)
+    // array.  It goes in chunks: while the DMA engine brings chunk k+1 the caller's thread moves
+    // chunk k on into the array, so the frame costs the slower of the two transfers, not their sum.
+    struct Chunk {
+        size_t off, len;
+    };
+    std::vector<Chunk> chunks;
+    // RT_HIP_COPY_CHUNK_KIB (tuning aid): chunk size in KiB.
+    static const char *chunk_env = getenv("RT_HIP_COPY_CHUNK_KIB");
+    const size_t chunk = chunk_env && atoll(chunk_env) > 0 ? (size_t)atoll(chunk_env) * 256 : RT_STAGED_COPY_CHUNK_PIXELS;
+    // Enqueues the copy of pixels [off, off + count) on `stream`, one event per chunk.
+    auto enqueue_copy = [&](size_t off, size_t count, hipStream_t stream) -> int {
+        for (size_t o = off; o < off + count; o += chunk) {
+            const size_t len = std::min(chunk, off + count - o);
+            if (ctx->copy_ev.size() <= chunks.size()) {
+                hipEvent_t e;
+                HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                ctx->copy_ev.push_back(e);
+            }
+            HIP_TRY(ctx, hipMemcpyAsync((direct ? pixels_out : ctx->staging) + o, root.out + o, len * sizeof(int32_t),
+                                        hipMemcpyDeviceToHost, stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->copy_ev[chunks.size()], stream));
+            chunks.push_back(Chunk{o, len});
+        }
+        return RT_OK;
+    };
+    // Waits for the chunks in order and, when staged, moves each on into the caller's array.
+    auto drain_copy = [&]() -> int {
+        for (size_t k = 0; k < chunks.size(); k++) {
+            HIP_TRY(ctx, hipEventSynchronize(ctx->copy_ev[k]));
+            if (!direct) copy_streaming(pixels_out + chunks[k].off, ctx->staging + chunks[k].off, chunks[k].len * sizeof(int32_t));
+        }
+        if (!direct) store_fence();   // the streaming stores are visible before the call returns
+        return RT_OK;
+    };
+
+    // One device, a large frame, nobody timing the kernels: render the frame as row blocks one
+    // after the other and copy each finished block while the next one renders.
+    // RT_HIP_FRAME_PARTS (tuning aid): number of blocks.
+    int parts = 1;
+    if (G == 1 && !ctx->profiling) {
+        static const char *parts_env = getenv("RT_HIP_FRAME_PARTS");
+        parts = parts_env ? atoi(parts_env)
+                          : total < RT_MIN_SPLIT_PIXELS ? 1 : std::max(2, (int)(total / RT_PART_PIXELS));
+        parts = std::max(1, std::min({parts, RT_MAX_FRAME_PARTS, h}));
+    }
+    if (parts > 1) {
+        if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int p = 0; p < parts; p++) {
+            const int y0 = (int)(((long long)h * p) / parts), y1 = (int)(((long long)h * (p + 1)) / parts);
+            const size_t off = (size_t)y0 * (size_t)w;
+            if ((rc = enqueue_rows(ctx, root, cam, w, h, contiguous_rows(y0, y1), max_depth, root.out + off, root.stream, p)) != RT_OK)
+                return rc;
+            if (!ctx->part_ev[p]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->part_ev[p], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventRecord(ctx->part_ev[p], root.stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->part_ev[p], 0));
+            if ((rc = enqueue_copy(off, (size_t)(y1 - y0) * (size_t)w, ctx->copy_stream)) != RT_OK) return rc;
+        }
+        if ((rc = drain_copy()) != RT_OK) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(root.stream));   // (done already: the copies waited for the kernels)
+        ctx->gather_ms = 0.0;
+        // Here the copy overlaps the kernels: what is reported is the time of the whole call.
+        ctx->copy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return check_schedule(ctx, root);
+    }
+
     // Device g renders its block; device 0 writes straight into the full frame.
     for (int g = 0; g < G; g++) {
         DeviceState &d = ctx->dev[g];
@@ -876,13 +1026,9 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, in
         }
         if (d.last_P > 0 && (rc = check_schedule(ctx, d)) != RT_OK) return rc;
     }
-    // D2H straight into the caller's array when it is page-locked (rt_pin_pixels), else into
-    // pinned staging and from there into the caller's (pageable) array.
     const auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(ctx, hipMemcpyAsync(direct ? pixels_out : ctx->staging, root.out, (size_t)total * sizeof(int32_t),
-                                hipMemcpyDeviceToHost, root.stream));
-    HIP_TRY(ctx, hipStreamSynchronize(root.stream));
-    if (!direct) memcpy(pixels_out, ctx->staging, (size_t)total * sizeof(int32_t));
+    if ((rc = enqueue_copy(0, (size_t)total, root.stream)) != RT_OK) return rc;
+    if ((rc = drain_copy()) != RT_OK) return rc;
     ctx->copy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;
 }
@@ -982,7 +1128,15 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out)
         HIP_TRY(ctx, hipDeviceSynchronize());
         std::vector<int> cnt(2 * (size_t)(d.last_depth + 2));
         DevCounters c{};
-        HIP_TRY(ctx, hipMemcpy(cnt.data(), d.frame.cnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+        if (d.snap_parts > 0) {   // a frame rendered in parts: the levels' record counts of all parts
+            for (int p = 0; p < d.snap_parts; p++) {
+                const int *part_cnt = reinterpret_cast<const int *>(d.outcome_snap + (size_t)p * FRAME_OUTCOME_BYTES +
+                                                                    sizeof(DevSched));
+                for (size_t i = 0; i < cnt.size(); i++) cnt[i] += part_cnt[i];
+            }
+        } else {
+            HIP_TRY(ctx, hipMemcpy(cnt.data(), d.frame.cnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+        }
         {
             static_assert(sizeof(DevCounters) % sizeof(uint64_t) == 0, "DevCounters is an array of 64-bit counts");
             constexpr size_t words = sizeof(DevCounters) / sizeof(uint64_t);

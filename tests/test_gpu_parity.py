@@ -364,6 +364,33 @@ def test_light_rays_may_stop_at_any_occluder(oracle, nspheres, nl, depth, size):
     assert np.array_equal(quick, counted)
 
 
+def test_large_frame_rendered_in_parts_with_overlapped_copy(oracle):
+    """Without profiling rt_render renders a frame of Config 3's size as row blocks and copies
+    each to the host while the next renders: same pixels and the same ray counts as the frame in
+    one piece (profiling on), sampled rows against the oracle, and a second call identical."""
+    fs = scene_1k().flatten()
+    cam, w, h, depth = Camera(), 3840, 2160, 4
+    with RenderContext() as c:
+        c.set_scene(fs)
+        parts = c.render(cam, w, h, depth)
+        st_parts = c.stats()
+        again = c.render(cam, w, h, depth)
+        c.set_profiling(True)
+        whole = c.render(cam, w, h, depth)
+        st_whole = c.stats()
+        small = c.render(cam, 320, 180, depth)   # back to a frame in one piece on the same context
+        assert c.stats()["rays_primary"] == 320 * 180
+    assert np.array_equal(parts, whole)
+    assert np.array_equal(again, whole)
+    for k in ("rays_primary", "rays_shadow", "rays_secondary", "shaded_hits"):
+        assert st_parts[k] == st_whole[k], k
+    rows = np.arange(0, h, 120)
+    ref, _ = oracle.render(fs, cam, w, h, max_depth=depth, row_step=120)
+    assert_parity(parts[rows], ref[rows], "frame rendered in parts")
+    ref_small, _ = oracle.render(fs, cam, 320, 180, max_depth=depth)
+    assert_parity(small, ref_small, "small frame after a frame in parts")
+
+
 def test_two_device_states_split_rows_and_gather(oracle):
     """rt_create with two device entries (the same GPU twice on a one-GPU box): the frame is
     split into two row blocks, the second is gathered into the first device's frame."""

@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--frames", type=int, default=5)
     ap.add_argument("--c5-size", default="1920x1080")
     ap.add_argument("--split-size", default="3840x2160", help="frame of the simulated row partitions")
+    ap.add_argument("--host-size", default="3840x2160", help="frame of the rt_render-into-host-memory measurement")
     args = ap.parse_args()
     want = set(args.configs.split(","))
     cam = Camera()
@@ -93,14 +94,14 @@ def main():
         import numpy as np
         ctx.set_scene(scene_1k().flatten())
         ctx.set_profiling(False)
-        w, h, depth = 3840, 2160, 4
+        (w, h), depth = (int(v) for v in args.host_size.split("x")), 4
         out = np.zeros(w * h, dtype=np.int32)
         for pinned in (False, True):
             if pinned:
                 try:
                     ctx.pin_pixels(out)
                 except Exception as e:   # systems that do not page-lock user memory
-                    print(json.dumps({"config": "C3 through rt_render into host memory",
+                    print(json.dumps({"config": f"{w}x{h} through rt_render into host memory",
                                       "framebuffer": "page-locked (rt_pin_pixels)", "refused": str(e)}), flush=True)
                     break
             ctx.render(cam, w, h, depth, out=out)
@@ -112,7 +113,7 @@ def main():
             ctx.render(cam, w, h, depth, out=out)
             st = ctx.stats()
             ctx.set_profiling(False)
-            print(json.dumps({"config": "C3 through rt_render into host memory",
+            print(json.dumps({"config": f"{w}x{h} through rt_render into host memory",
                               "framebuffer": "page-locked (rt_pin_pixels)" if pinned else "pageable",
                               "ms_per_frame": round(ms, 3), "kernel_ms": round(st["kernel_ms"], 3),
                               "copy_ms": round(st["copy_ms"], 3)}), flush=True)
