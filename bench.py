@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from raytracer_amd import Camera, RenderContext, scene_1k  # noqa: E402
-from raytracer_amd.distributed import FrameGatherer, render_block  # noqa: E402
+from raytracer_amd.distributed import FramePipeline, render_block  # noqa: E402
 
 WIDTH, HEIGHT, MAX_DEPTH = 3840, 2160, 4
 PEAK_FP32_TFLOPS = 157.3
@@ -102,11 +102,13 @@ def main() -> None:
     flat = scene_1k().flatten()
     ctx = RenderContext([local_rank])
     ctx.set_scene(flat)
-    gatherer = FrameGatherer(WIDTH, HEIGHT, rank, world, torch.device("cuda", local_rank))
+    # Several ranks: two frames in flight, so that a frame's gather (and rank 0's row
+    # permutation) runs while the next frame renders.
+    pipeline = FramePipeline(WIDTH, HEIGHT, rank, world, torch.device("cuda", local_rank),
+                             depth=2 if world > 1 else 1)
 
     def step() -> None:
-        render_block(ctx, cam, WIDTH, HEIGHT, MAX_DEPTH, gatherer)
-        gatherer.gather()
+        pipeline.render_frame(ctx, cam, MAX_DEPTH)
 
     def fence() -> None:
         torch.cuda.synchronize()
@@ -125,7 +127,7 @@ def main() -> None:
 
     # One more frame with the device-side counters and event timing on (they cost ~2 %).
     ctx.set_profiling(True)
-    render_block(ctx, cam, WIDTH, HEIGHT, MAX_DEPTH, gatherer)
+    render_block(ctx, cam, WIDTH, HEIGHT, MAX_DEPTH, pipeline.begin())
     st = ctx.stats()  # synchronises; counters and HIP-event times of this rank's frame
     keys = ("rays_primary", "rays_shadow", "rays_secondary", "shaded_hits", "sphere_tests",
             "plane_tests", "triangle_tests", "filter_ray_tests", "filter_origin_terms", "exact_candidates",
@@ -177,7 +179,8 @@ def main() -> None:
                 "width": WIDTH, "height": HEIGHT, "max_depth": MAX_DEPTH,
                 "spheres": ns, "planes": npl, "lights": flat.num_lights,
                 "partition": ("whole frame on one GPU" if world == 1 else
-                              f"every {world}th band of 16 rows per rank, RCCL gather to rank 0"),
+                              f"every {world}th band of 16 rows per rank, RCCL gather to rank 0, "
+                              "two frames in flight (a frame's gather overlaps the next frame's rendering)"),
                 "rays_per_frame": int(rays),
                 "exact_candidates_rank0": int(st["exact_candidates"]),
             },

@@ -125,6 +125,54 @@ class FrameGatherer:
                     self.frame[a:b].copy_(buf[: b - a])
 
 
+class FramePipeline:
+    """Frames in flight: while frame i is gathered (and permuted on rank 0), frame i + 1 renders.
+
+    ``depth`` FrameGatherers take turns, each with its own buffers and stream.  Rendering is
+    kept to one frame at a time (a render context has one set of ray queues): a slot's stream
+    waits for the previous frame's kernels before it renders, not for the previous frame's
+    collective.  Collectives are issued in frame order on every rank.  The frame tensor that
+    ``render_frame`` returns on rank 0 is overwritten ``depth`` frames later.
+    """
+
+    def __init__(self, width: int, height: int, rank: int, world: int, device: torch.device,
+                 group: Optional[dist.ProcessGroup] = None, interleave: bool = True,
+                 band_rows: int = BAND_ROWS, depth: int = 2):
+        if depth < 1:
+            raise ValueError("depth must be at least 1")
+        self.width, self.height = width, height
+        self.slots = [FrameGatherer(width, height, rank, world, device, group, interleave, band_rows)
+                      for _ in range(depth)]
+        self._count = 0
+        self._rendered: Optional[torch.cuda.Event] = None
+
+    def begin(self) -> FrameGatherer:
+        """The next slot, its stream ordered behind the rendering of the previous frame: fill
+        ``slot.block`` on ``slot.stream`` (``render_block``), then call ``finish(slot)``."""
+        g = self.slots[self._count % len(self.slots)]
+        self._count += 1
+        if g.stream is not None and self._rendered is not None:
+            g.stream.wait_event(self._rendered)
+        return g
+
+    def finish(self, g: FrameGatherer) -> Optional[torch.Tensor]:
+        """Marks the slot's rendering as enqueued and enqueues its gather."""
+        if g.stream is not None:
+            self._rendered = torch.cuda.Event()
+            self._rendered.record(g.stream)
+        return g.gather()
+
+    def render_frame(self, ctx, camera, max_depth: int) -> Optional[torch.Tensor]:
+        g = self.begin()
+        render_block(ctx, camera, self.width, self.height, max_depth, g)
+        return self.finish(g)
+
+    def synchronize(self) -> None:
+        for g in self.slots:
+            if g.stream is not None:
+                g.stream.synchronize()
+
+
 def render_block(ctx, camera, width: int, height: int, max_depth: int, gatherer: FrameGatherer) -> None:
     """Enqueue this rank's part of the frame into ``gatherer.block`` (device memory) on the
     gatherer's stream."""

@@ -47,6 +47,45 @@ def _worker(rank: int, world: int, port: int, w: int, h: int, interleave: bool, 
     dist.destroy_process_group()
 
 
+def _pipeline_worker(rank: int, world: int, port: int, w: int, h: int, outdir: str):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from raytracer_amd import Camera, default_scene
+    from raytracer_amd.distributed import FramePipeline, band_rows_of
+    fs = default_scene().flatten()
+    pipe = FramePipeline(w, h, rank, world, torch.device("cpu"), band_rows=4, depth=2)
+    mine = band_rows_of(h, rank, world, 4)
+    frames = []
+    for i in range(5):   # five different frames through two slots
+        img, _ = O.render(fs, Camera(position=(0.1 * i, 0.0, 0.0)), w, h, nthreads=1)
+        slot = pipe.begin()
+        slot.block.copy_(torch.from_numpy(img[mine]))
+        frame = pipe.finish(slot)
+        if rank == 0:
+            frames.append(frame.numpy().copy())
+        else:
+            assert frame is None
+    pipe.synchronize()
+    if rank == 0:
+        np.save(os.path.join(outdir, "frames.npy"), np.stack(frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipeline_of_two_frames_in_flight(tmp_path, oracle):
+    from raytracer_amd import Camera, default_scene
+    w, h, world = 48, 30, 2
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), w, h, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "frames.npy")
+    fs = default_scene().flatten()
+    for i in range(5):
+        ref, _ = oracle.render(fs, Camera(position=(0.1 * i, 0.0, 0.0)), w, h)
+        assert np.array_equal(got[i], ref), i
+
+
 @pytest.mark.parametrize("world,h,interleave", [(2, 48, False), (2, 37, False), (3, 50, False),
                                                 (2, 48, True), (2, 37, True), (3, 50, True), (3, 7, True)])
 def test_gather_reassembles_the_frame(tmp_path, oracle, world, h, interleave):

@@ -391,6 +391,25 @@ def test_large_frame_rendered_in_parts_with_overlapped_copy(oracle):
     assert_parity(small, ref_small, "small frame after a frame in parts")
 
 
+def test_pipeline_slots_alternate_streams_on_one_context(ctx, oracle):
+    """FramePipeline on one rank: consecutive frames go through two slots (two streams, two
+    frame buffers) of ONE render context; each slot's stream waits for the previous frame's
+    kernels, so every frame is complete and a slot's frame survives the next frame."""
+    import torch
+    from raytracer_amd.distributed import FramePipeline
+    fs = scene_1k().flatten()
+    ctx.set_scene(fs)
+    w, h, depth = 640, 360, 3
+    pipe = FramePipeline(w, h, 0, 1, torch.device("cuda", 0), depth=2)
+    cams = [Camera(position=(0.05 * i, 0.0, 0.0)) for i in range(6)]
+    frames = [pipe.render_frame(ctx, cam, depth) for cam in cams]
+    pipe.synchronize()
+    assert frames[4].data_ptr() != frames[5].data_ptr() and frames[3].data_ptr() == frames[5].data_ptr()
+    for i in (4, 5):   # the last frame of either slot
+        ref, _ = oracle.render(fs, cams[i], w, h, max_depth=depth)
+        assert_parity(frames[i].cpu().numpy(), ref, f"pipelined frame {i}")
+
+
 def test_two_device_states_split_rows_and_gather(oracle):
     """rt_create with two device entries (the same GPU twice on a one-GPU box): the frame is
     split into two row blocks, the second is gathered into the first device's frame."""
