@@ -166,10 +166,12 @@ int rt_device_count(void);
 
 /*
  * Create a context on the given devices (device_ids == NULL or n_devices <= 0:
- * device 0 only).  With more than one device, rt_render() splits the frame into
- * contiguous row blocks, one per device — the image-space partition the reference
- * already uses for its thread pool (Parallel.For over rows, MyApplication.cs:408)
- * — and gathers the blocks on the first device.
+ * device 0 only).  With more than one device, rt_render() splits the frame by rows —
+ * the image-space partition the reference already uses for its thread pool
+ * (Parallel.For over rows, MyApplication.cs:408): device g of G takes the bands g,
+ * g + G, ... of 16 rows (contiguous blocks when the frame has fewer than 2 G bands),
+ * and every device writes its bands into the first device's frame with one strided
+ * copy.
  * Replaces: the Raytracer constructor (MyApplication.cs:392-400).
  */
 int rt_create(rt_ctx **out, const int *device_ids, int n_devices);

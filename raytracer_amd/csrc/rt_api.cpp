@@ -40,6 +40,9 @@ constexpr size_t FRAME_OUTCOME_BYTES = sizeof(DevSched) + 2 * RT_DEV_MAX_LEVELS 
 // ms; 1920x1080: 0.86 -> 1.02 ms), and beyond that blocks of ~4 M pixels are best (3840x2160:
 // two blocks 2.40 ms, four 2.52; 7680x4320: eight blocks 7.7 ms against 10.6 in one piece).
 constexpr int RT_MAX_FRAME_PARTS = 8;
+// Rows per band of the interleaved partition over several devices: one wave of the primary
+// kernel covers 16 x 16 pixels.
+constexpr int RT_BAND_ROWS = 16;
 constexpr long long RT_MIN_SPLIT_PIXELS = 3000000, RT_PART_PIXELS = 4000000;
 
 thread_local std::string g_create_error;
@@ -61,6 +64,8 @@ struct DeviceState {
     size_t cap_slots = 0, cap_mask = 0;
     int32_t *out = nullptr;  // device framebuffer block of this device
     size_t cap_out = 0;
+    int32_t *bands = nullptr;  // this device's bands of an interleaved partition, stacked (rt_render, several devices)
+    size_t cap_bands = 0;
 
     // last call
     int last_P = 0, last_depth = 0;
@@ -756,6 +761,7 @@ void rt_destroy(rt_ctx *ctx)
             if (d.ev[k]) (void)hipEventDestroy(d.ev[k]);
         if (d.stream) (void)hipStreamDestroy(d.stream);
         if (d.outcome_snap) (void)hipHostFree(d.outcome_snap);
+        if (d.bands) (void)hipFree(d.bands);
     }
     if (ctx->staging) (void)hipHostFree(ctx->staging);
     if (!ctx->dev.empty()) (void)hipSetDevice(ctx->dev[0].device);
@@ -983,43 +989,83 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, in
         return check_schedule(ctx, root);
     }
 
-    // Device g renders its block; device 0 writes straight into the full frame.
-    for (int g = 0; g < G; g++) {
-        DeviceState &d = ctx->dev[g];
-        const int y0 = ctx->last_rows[g], y1 = ctx->last_rows[g + 1];
-        const size_t block = (size_t)(y1 - y0) * (size_t)w;
-        int32_t *target = root.out + (size_t)y0 * (size_t)w;
-        if (g > 0) {
+    // Several devices and enough rows: device g takes the bands g, g + G, ... of RT_BAND_ROWS rows
+    // (rows cost very different amounts; interleaved, every device gets its share of the
+    // expensive ones), renders them stacked into a block of its own and writes them into device
+    // 0's frame with ONE strided copy: source pitch = a band, destination pitch = G bands.
+    const bool interleaved = G > 1 && h >= 2 * G * RT_BAND_ROWS;
+    if (interleaved) {
+        const size_t band_px = (size_t)RT_BAND_ROWS * (size_t)w;
+        const int nbands = (h + RT_BAND_ROWS - 1) / RT_BAND_ROWS;
+        for (int g = 0; g < G; g++) {
+            DeviceState &d = ctx->dev[g];
+            const RowSet rs{0, rows_of_part(h, RT_BAND_ROWS, g, G), RT_BAND_ROWS, G, g};
+            const size_t block = (size_t)rs.rows * (size_t)w;
             HIP_TRY(ctx, hipSetDevice(d.device));
-            if (block > d.cap_out) {
-                if (d.out) (void)hipFree(d.out);
-                d.out = nullptr;
-                d.cap_out = 0;
-                HIP_TRY(ctx, hipMalloc((void **)&d.out, std::max<size_t>(block, 1) * sizeof(int32_t)));
-                d.cap_out = block;
+            if (block > d.cap_bands) {
+                if (d.bands) (void)hipFree(d.bands);
+                d.bands = nullptr;
+                d.cap_bands = 0;
+                HIP_TRY(ctx, hipMalloc((void **)&d.bands, block * sizeof(int32_t)));
+                d.cap_bands = block;
             }
-            target = d.out;
+            if ((rc = enqueue_rows(ctx, d, cam, w, h, rs, max_depth, d.bands, d.stream)) != RT_OK) return rc;
         }
-        if ((rc = enqueue_rows(ctx, d, cam, w, h, contiguous_rows(y0, y1), max_depth, target, d.stream)) != RT_OK) return rc;
-    }
-    // Gather: every other device writes its block into device 0's frame (one copy per
-    // device, each over its own link), then one copy to the host.
-    for (int g = 1; g < G; g++) {
-        DeviceState &d = ctx->dev[g];
-        const int y0 = ctx->last_rows[g], y1 = ctx->last_rows[g + 1];
-        const size_t bytes = (size_t)(y1 - y0) * (size_t)w * sizeof(int32_t);
-        if (bytes == 0) continue;
-        HIP_TRY(ctx, hipSetDevice(d.device));
-        HIP_TRY(ctx, hipMemcpyPeerAsync(root.out + (size_t)y0 * (size_t)w, root.device, d.out, d.device, bytes,
-                                        d.stream));
-        if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[4], d.stream));
+        for (int g = 0; g < G; g++) {
+            DeviceState &d = ctx->dev[g];
+            const int mine = (nbands - g + G - 1) / G;                      // bands of device g
+            const bool short_last = h % RT_BAND_ROWS != 0 && (nbands - 1) % G == g;
+            const int full = short_last ? mine - 1 : mine;                  // of full height
+            HIP_TRY(ctx, hipSetDevice(d.device));
+            if (full > 0)
+                HIP_TRY(ctx, hipMemcpy2DAsync(root.out + (size_t)g * band_px, (size_t)G * band_px * sizeof(int32_t), d.bands,
+                                              band_px * sizeof(int32_t), band_px * sizeof(int32_t), (size_t)full,
+                                              hipMemcpyDeviceToDevice, d.stream));
+            if (short_last)
+                HIP_TRY(ctx, hipMemcpyAsync(root.out + (size_t)(nbands - 1) * band_px, d.bands + (size_t)full * band_px,
+                                            (size_t)(h - (nbands - 1) * RT_BAND_ROWS) * (size_t)w * sizeof(int32_t),
+                                            hipMemcpyDeviceToDevice, d.stream));
+            if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[4], d.stream));
+        }
+    } else {
+        // Device g renders its block; device 0 writes straight into the full frame.
+        for (int g = 0; g < G; g++) {
+            DeviceState &d = ctx->dev[g];
+            const int y0 = ctx->last_rows[g], y1 = ctx->last_rows[g + 1];
+            const size_t block = (size_t)(y1 - y0) * (size_t)w;
+            int32_t *target = root.out + (size_t)y0 * (size_t)w;
+            if (g > 0) {
+                HIP_TRY(ctx, hipSetDevice(d.device));
+                if (block > d.cap_out) {
+                    if (d.out) (void)hipFree(d.out);
+                    d.out = nullptr;
+                    d.cap_out = 0;
+                    HIP_TRY(ctx, hipMalloc((void **)&d.out, std::max<size_t>(block, 1) * sizeof(int32_t)));
+                    d.cap_out = block;
+                }
+                target = d.out;
+            }
+            if ((rc = enqueue_rows(ctx, d, cam, w, h, contiguous_rows(y0, y1), max_depth, target, d.stream)) != RT_OK) return rc;
+        }
+        // Gather: every other device writes its block into device 0's frame (one copy per
+        // device, each over its own link), then one copy to the host.
+        for (int g = 1; g < G; g++) {
+            DeviceState &d = ctx->dev[g];
+            const int y0 = ctx->last_rows[g], y1 = ctx->last_rows[g + 1];
+            const size_t bytes = (size_t)(y1 - y0) * (size_t)w * sizeof(int32_t);
+            if (bytes == 0) continue;
+            HIP_TRY(ctx, hipSetDevice(d.device));
+            HIP_TRY(ctx, hipMemcpyPeerAsync(root.out + (size_t)y0 * (size_t)w, root.device, d.out, d.device, bytes,
+                                            d.stream));
+            if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[4], d.stream));
+        }
     }
     ctx->gather_ms = 0.0;
     for (int g = G - 1; g >= 0; g--) {
         DeviceState &d = ctx->dev[g];
         HIP_TRY(ctx, hipSetDevice(d.device));
         HIP_TRY(ctx, hipStreamSynchronize(d.stream));
-        if (g > 0 && d.timed && d.last_P > 0) {
+        if ((g > 0 || interleaved) && d.timed && d.last_P > 0) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, d.ev[3], d.ev[4]) == hipSuccess)
                 ctx->gather_ms = std::max(ctx->gather_ms, (double)ms);

@@ -411,16 +411,25 @@ def test_pipeline_slots_alternate_streams_on_one_context(ctx, oracle):
 
 
 def test_two_device_states_split_rows_and_gather(oracle):
-    """rt_create with two device entries (the same GPU twice on a one-GPU box): the frame is
-    split into two row blocks, the second is gathered into the first device's frame."""
+    """rt_create with several device entries (the same GPU several times on a one-GPU box): tall
+    frames are split into interleaved bands of 16 rows and gathered with one strided copy per
+    device (a short last band, exact bands, three devices), short frames into contiguous blocks."""
     fs = default_scene().flatten()
     cam = Camera()
     with RenderContext([0, 0]) as two:
         two.set_profiling(True)
         two.set_scene(fs)
-        for (w, h) in [(200, 150), (64, 33)]:
+        for (w, h) in [(200, 150), (96, 128), (64, 33)]:
             gpu = two.render(cam, w, h, 5)
-            ref, _ = oracle.render(fs, cam, w, h, max_depth=5)
+            ref, cnt = oracle.render(fs, cam, w, h, max_depth=5)
             assert np.array_equal(gpu, ref), (w, h)
+            st = two.stats()
+            assert st["rays_shadow"] == cnt["rays_shadow"] and st["sphere_tests"] == cnt["sphere_tests"]
         assert two.stats()["num_devices"] == 2
         assert two.stats()["rays_primary"] == 64 * 33
+    with RenderContext([0, 0, 0]) as three:
+        three.set_scene(fs)
+        for (w, h) in [(120, 100), (120, 161)]:
+            gpu = three.render(cam, w, h, 5)
+            ref, _ = oracle.render(fs, cam, w, h, max_depth=5)
+            assert np.array_equal(gpu, ref), (w, h)
