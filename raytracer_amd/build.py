@@ -56,7 +56,7 @@ TOOLS_DIR = os.path.join(os.path.dirname(HERE), "tools")
 
 def build_tools(force: bool = False) -> None:
     """Standalone gfx950 programs under tools/ (microbenchmarks)."""
-    for src in ("valu_bench.hip",):
+    for src in ("valu_bench.hip", "valu_issue_bench.hip", "pk_loop_bench.hip", "filter_loop_bench.hip", "prio_bench.hip"):
         path = os.path.join(TOOLS_DIR, src)
         exe = path[: -len(".hip")]
         if not os.path.exists(path):

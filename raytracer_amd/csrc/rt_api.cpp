@@ -24,6 +24,7 @@ namespace {
 
 // Below this many level-0 tiles per resident workgroup a frame is bound by its chain of levels.
 constexpr int RT_CHAIN_BOUND_TILES_PER_WORKGROUP = 8;
+constexpr int RT_CHAIN_RESERVED_TILES_PER_WORKGROUP = 6;
 
 // Counter slots + level schedule + two record counts per level (DevFrame::counters, sched, cnt).
 constexpr size_t FRAME_CONTROL_BYTES =
@@ -652,6 +653,15 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     d.frame.first_lights = tiles0 >= RT_CHAIN_BOUND_TILES_PER_WORKGROUP * d.resident_blocks ? shared_walk : 0;
     if (first_env) d.frame.first_lights = std::max(0, std::min(atoi(first_env), shared_walk));
     d.frame.any_hit = ctx->profiling ? 0 : 1;
+    // On still smaller frames (measured: below ~6 tiles per resident workgroup; 4K / 8 GPUs has 4)
+    // it pays to reserve the oldest workgroup of every compute unit for the chain: a SIMD issues
+    // for its oldest waves first, so a chain tile in a young workgroup crawls while its elders
+    // have work.  1/8 of the 4K frame: 0.397 -> 0.362 ms; 1/4 (8 tiles per workgroup): 0.547 ->
+    // 0.571, hence the bound.  RT_HIP_CHAIN_POLICY=0/1 (tuning aid) overrides.
+    static const char *policy_env = getenv("RT_HIP_CHAIN_POLICY");
+    d.frame.chain_policy = policy_env ? (atoi(policy_env) != 0)
+                                      : tiles0 < RT_CHAIN_RESERVED_TILES_PER_WORKGROUP * d.resident_blocks;
+    d.frame.num_cus = d.num_cus;
     const DevFrame &f = d.frame;
     if (part > 0) HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, FRAME_OUTCOME_BYTES, stream));
     else HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, FRAME_CONTROL_BYTES, stream));

@@ -116,6 +116,7 @@ struct DevCounters {
 
 // Tile schedule of k_trace_levels (rt_kernels.hip), zeroed before every render call.
 #define RT_DEV_MAX_LEVELS 18   // RT_MAX_DEPTH + 2
+#define RT_DEV_CU_SLOTS 2048   // 8 XCCs x 256 (SE, SH, CU) codes
 struct DevSched {
     int next_a[RT_DEV_MAX_LEVELS];   // next unclaimed tile of level k's reflecting records
     int next_b[RT_DEV_MAX_LEVELS];   // ... of its plain records
@@ -127,6 +128,9 @@ struct DevSched {
     // printed by the host when RT_HIP_SCHED_TRACE is set.
     unsigned long long t_first, t_last;
     unsigned long long t_open[RT_DEV_MAX_LEVELS];
+    // Workgroups of k_trace_levels that have started on each compute unit (index: XCC id, then
+    // the SE / SH / CU bits of HW_ID): a workgroup's count on arrival is its age rank there.
+    int cu_arrivals[RT_DEV_CU_SLOTS];
 };
 
 // Hit records: the bounce stack of every pixel, kept in HBM.  Level k of the frame
@@ -155,6 +159,9 @@ struct DevFrame {
     int mask_words;        // ceil(nl / 32), at least 1
     int first_lights;      // lights traced in the same walk as a record's reflection ray (rt_kernels.hip, walks_of)
     int any_hit;           // 1: a light ray may stop at ANY occluder (the Intersect-call counters are not wanted)
+    int chain_policy;      // 1: k_trace_levels keeps the tiles the next level waits for to the workgroups that
+                           // arrived first on their compute units, and the first of each free for them
+    int num_cus;
 };
 
 // Launch wrappers (rt_kernels.hip).  All enqueue on `stream` and return at once.

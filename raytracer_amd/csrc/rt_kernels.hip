@@ -1410,6 +1410,7 @@ __device__ __forceinline__ int sched_load(const int *p)
 
 // Thread 0's view of the schedule.
 struct Taker {
+    int rank;             // how many workgroups of the launch were on this compute unit before this one
     int seen_open;        // levels <= seen_open: record counts read
     int b_level;          // lowest level whose B queue may still hold an unclaimed tile
     bool a_left;          // level seen_open may still hold an unclaimed A tile
@@ -1436,7 +1437,13 @@ k_trace_levels(DevScene s, DevFrame f)
 #ifdef RT_PHASE_CLOCKS
     pc.t_last = __builtin_readcyclecounter();
 #endif
-    Taker tk = {-1, 0, false, 0u};
+    Taker tk = {0, -1, 0, false, 0u};
+    if (threadIdx.x == 0 && f.chain_policy) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        tk.rank = atomicAdd(&sc->cu_arrivals[((xcc & 7u) << 8) | ((hw >> 8) & 255u)], 1);
+    }
 #ifdef RT_SCHED_TIMELINE   // profiling builds only: two atomics per workgroup on one word cost ~20 us
     if (threadIdx.x == 0) atomicCAS(&sc->t_first, 0ull, (unsigned long long)wall_clock64());
 #endif
@@ -1447,10 +1454,17 @@ k_trace_levels(DevScene s, DevFrame f)
                 // What this workgroup believes is claimable, A tiles of the newest level first.
                 int *ctr = nullptr;
                 int cand_kind = SCHED_JOB_EXIT, cand_lvl = 0, cand_jobs = 0;
-                if (tk.a_left) {
+                // The SIMDs issue for their oldest waves first (s_setprio changes nothing there):
+                // a tile the next level waits for belongs in a workgroup that arrived early on
+                // its compute unit — the first of each while they suffice for the level's tiles.
+                const bool chain_wg = !f.chain_policy || tk.rank == 0 ||
+                                      (tk.seen_open >= 0 && tk.rank * f.num_cus < ((lv_a[tk.seen_open] + 255) >> 8));
+                if (tk.a_left && chain_wg) {
                     ctr = &sc->next_a[tk.seen_open];
                     cand_kind = SCHED_JOB_A, cand_lvl = tk.seen_open, cand_jobs = (lv_a[tk.seen_open] + 255) >> 8;
-                } else {
+                } else if (!(f.chain_policy && tk.rank == 0 && tk.seen_open >= 0 && lv_a[tk.seen_open] > 0)) {
+                    // (under the policy, while the chain lasts, the first workgroup of a compute unit
+                    // keeps itself free for the next level's tiles instead of taking a plain job)
                     while (tk.b_level <= tk.seen_open && lv_jobs[tk.b_level] < 0) tk.b_level++;
                     if (tk.b_level <= tk.seen_open) {
                         ctr = &sc->next_b[tk.b_level];
