@@ -123,6 +123,7 @@ struct DevSched {
     int done_a[RT_DEV_MAX_LEVELS];   // finished reflecting tiles of level k
     int open_level;                  // levels <= open_level have their final record counts
     int error;                       // set when a workgroup gave up waiting for a level
+    int next_primary;                // k_primary: tiles handed out beyond each workgroup's first
     // Timeline of the launch in ticks of the constant 100 MHz clock (wall_clock64): first claim,
     // the opening of every level, last exit.  Written only by builds with -DRT_SCHED_TIMELINE and
     // printed by the host when RT_HIP_SCHED_TRACE is set.

@@ -971,7 +971,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     FilterWork fw = {0, 0, 0};
     PhaseClock pc = {};
     const unsigned all_live[4] = {~0u, ~0u, ~0u, ~0u};
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // A workgroup's first tile is its index; the others are claimed from a counter (tiles cost
+    // very different amounts), each claim sent before the tile it follows so that its answer
+    // travels while that tile is traced.  blk[10], blk[11]: the answer, alternating per trip.
+    int trip = 0;
+    for (int tile = blockIdx.x; tile < ntiles; trip++) {
+        int claimed = 0;
+        if (threadIdx.x == 0) claimed = (int)gridDim.x + atomicAdd(&f.sched->next_primary, 1);
         const int tx = tile % tiles_x, ty = tile / tiles_x;
         const int x0 = tx * 32 + (wave & 1) * 16 + (lane & 7) * 2;
         const int y0 = ty * 32 + (wave >> 1) * 16 + (lane >> 3) * 2;   // row of the output block
@@ -1056,7 +1062,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
             rec_hit[k] = add3(o, scale3(d[k], c.t));
             if (inside[k] && !hit) pixels[pix] = 0;  // MyApplication.cs:423
         }
-        push_records<PRIM_PX, false>(f, s, 0, blk, rec_valid, rec_prim, rec_hit, d, rec_parent);
+        if (threadIdx.x == 0) blk[10 + (trip & 1)] = claimed;
+        push_records<PRIM_PX, false>(f, s, 0, blk, rec_valid, rec_prim, rec_hit, d, rec_parent);   // (barriers)
+        tile = blk[10 + (trip & 1)];
     }
     // Counter words in the order of DevCounters; the filter's counts are the same in every lane.
     const unsigned long long cand_total = (unsigned long long)wave_sum(fw.candidates);
