@@ -27,8 +27,11 @@ constexpr int RT_CHAIN_BOUND_TILES_PER_WORKGROUP = 8;
 constexpr int RT_CHAIN_RESERVED_TILES_PER_WORKGROUP = 6;
 
 // Counter slots + level schedule + two record counts per level (DevFrame::counters, sched, cnt).
-constexpr size_t FRAME_CONTROL_BYTES =
+constexpr size_t FRAME_CONTROL_USED =
     RT_COUNTER_SLOTS * sizeof(DevCounters) + sizeof(DevSched) + 2 * RT_DEV_MAX_LEVELS * sizeof(int);
+// (rounded so that the fill that clears it is one kernel: a size that is no multiple of 16 bytes
+// gets a second fill for its tail)
+constexpr size_t FRAME_CONTROL_BYTES = (FRAME_CONTROL_USED + 255) / 256 * 256;
 
 // Level schedule + record counts: the part of the control block a render call leaves its
 // outcome in (has the schedule stalled, how many records did each level hold).
@@ -663,7 +666,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
                                       : tiles0 < RT_CHAIN_RESERVED_TILES_PER_WORKGROUP * d.resident_blocks;
     d.frame.num_cus = d.num_cus;
     const DevFrame &f = d.frame;
-    if (part > 0) HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, FRAME_OUTCOME_BYTES, stream));
+    if (part > 0) HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, FRAME_CONTROL_BYTES - RT_COUNTER_SLOTS * sizeof(DevCounters), stream));
     else HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, FRAME_CONTROL_BYTES, stream));
     d.timed = ctx->profiling;
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));

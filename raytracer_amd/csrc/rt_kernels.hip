@@ -1425,7 +1425,10 @@ struct Taker {
     unsigned spins;
 };
 
-template <int LCMAX, bool MULTI>
+// RESERVE: the chain tiles are kept to the oldest workgroups of the compute units (see the claim
+// loop); an instance of its own, because the bookkeeping costs the plain instance ~1.5 % of a
+// large frame in register pressure.
+template <int LCMAX, bool MULTI, bool RESERVE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 k_trace_levels(DevScene s, DevFrame f)
 {
@@ -1446,11 +1449,13 @@ k_trace_levels(DevScene s, DevFrame f)
     pc.t_last = __builtin_readcyclecounter();
 #endif
     Taker tk = {0, -1, 0, false, 0u};
-    if (threadIdx.x == 0 && f.chain_policy) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        tk.rank = atomicAdd(&sc->cu_arrivals[((xcc & 7u) << 8) | ((hw >> 8) & 255u)], 1);
+    if constexpr (RESERVE) {
+        if (threadIdx.x == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            tk.rank = atomicAdd(&sc->cu_arrivals[((xcc & 7u) << 8) | ((hw >> 8) & 255u)], 1);
+        }
     }
 #ifdef RT_SCHED_TIMELINE   // profiling builds only: two atomics per workgroup on one word cost ~20 us
     if (threadIdx.x == 0) atomicCAS(&sc->t_first, 0ull, (unsigned long long)wall_clock64());
@@ -1465,14 +1470,17 @@ k_trace_levels(DevScene s, DevFrame f)
                 // The SIMDs issue for their oldest waves first (s_setprio changes nothing there):
                 // a tile the next level waits for belongs in a workgroup that arrived early on
                 // its compute unit — the first of each while they suffice for the level's tiles.
-                const bool chain_wg = !f.chain_policy || tk.rank == 0 ||
-                                      (tk.seen_open >= 0 && tk.rank * f.num_cus < ((lv_a[tk.seen_open] + 255) >> 8));
+                bool chain_wg = true, keep_free = false;
+                if constexpr (RESERVE) {
+                    chain_wg = tk.rank == 0 || (tk.seen_open >= 0 && tk.rank * f.num_cus < ((lv_a[tk.seen_open] + 255) >> 8));
+                    // While the chain lasts the first workgroup of a compute unit keeps itself free
+                    // for the next level's tiles instead of taking a plain job.
+                    keep_free = tk.rank == 0 && tk.seen_open >= 0 && lv_a[tk.seen_open] > 0;
+                }
                 if (tk.a_left && chain_wg) {
                     ctr = &sc->next_a[tk.seen_open];
                     cand_kind = SCHED_JOB_A, cand_lvl = tk.seen_open, cand_jobs = (lv_a[tk.seen_open] + 255) >> 8;
-                } else if (!(f.chain_policy && tk.rank == 0 && tk.seen_open >= 0 && lv_a[tk.seen_open] > 0)) {
-                    // (under the policy, while the chain lasts, the first workgroup of a compute unit
-                    // keeps itself free for the next level's tiles instead of taking a plain job)
+                } else if (!keep_free) {
                     while (tk.b_level <= tk.seen_open && lv_jobs[tk.b_level] < 0) tk.b_level++;
                     if (tk.b_level <= tk.seen_open) {
                         ctr = &sc->next_b[tk.b_level];
@@ -1877,10 +1885,14 @@ void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting,
 }
 
 typedef void (*trace_levels_kernel)(DevScene, DevFrame);
-static trace_levels_kernel trace_levels_for(const DevScene &s)
+static trace_levels_kernel trace_levels_for(const DevScene &s, bool reserve = false)
 {
-    if (multi_chunk(s)) return s.nl >= 4 ? k_trace_levels<4, true> : k_trace_levels<2, true>;
-    return s.nl >= 4 ? k_trace_levels<4, false> : k_trace_levels<2, false>;
+    if (reserve) {
+        if (multi_chunk(s)) return s.nl >= 4 ? k_trace_levels<4, true, true> : k_trace_levels<2, true, true>;
+        return s.nl >= 4 ? k_trace_levels<4, false, true> : k_trace_levels<2, false, true>;
+    }
+    if (multi_chunk(s)) return s.nl >= 4 ? k_trace_levels<4, true, false> : k_trace_levels<2, true, false>;
+    return s.nl >= 4 ? k_trace_levels<4, false, false> : k_trace_levels<2, false, false>;
 }
 
 int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus)
@@ -1896,7 +1908,7 @@ int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus)
 
 void rtk_trace_levels(const DevScene &s, const DevFrame &f, int grid_blocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(trace_levels_for(s), dim3(grid_blocks), dim3(256), 0, stream, s, f);
+    hipLaunchKernelGGL(trace_levels_for(s, f.chain_policy != 0), dim3(grid_blocks), dim3(256), 0, stream, s, f);
 }
 
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
