@@ -391,6 +391,23 @@ def test_large_frame_rendered_in_parts_with_overlapped_copy(oracle):
     assert_parity(small, ref_small, "small frame after a frame in parts")
 
 
+@pytest.mark.parametrize("size,offset", [((1024, 768), 1), ((1024, 768), 3), ((3840, 2160), 1), ((333, 217), 2)])
+def test_framebuffer_at_any_alignment(size, offset):
+    """pixels_out is whatever address the host's array has (a managed int[] is 8-byte aligned at
+    best): the chunked copy with its 16-byte streaming stores must fill exactly the frame, at
+    any 4-byte alignment, for one chunk, several chunks and a frame rendered in parts."""
+    fs = scene_1k().flatten()
+    cam, (w, h), depth = Camera(), size, 2
+    with RenderContext() as c:
+        c.set_scene(fs)
+        aligned = c.render(cam, w, h, depth)
+        guard = np.full(w * h + 8, 0x5A5A5A5A, dtype=np.int32)
+        out = guard[offset:offset + w * h]
+        c.render(cam, w, h, depth, out=out)
+    assert np.array_equal(out.reshape(h, w), aligned)
+    assert np.all(guard[:offset] == 0x5A5A5A5A) and np.all(guard[offset + w * h:] == 0x5A5A5A5A)
+
+
 def test_pipeline_slots_alternate_streams_on_one_context(ctx, oracle):
     """FramePipeline on one rank: consecutive frames go through two slots (two streams, two
     frame buffers) of ONE render context; each slot's stream waits for the previous frame's
