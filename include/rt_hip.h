@@ -108,11 +108,12 @@ typedef struct rt_scene {
  * sphere/plane/triangle_tests count the Intersect calls the reference's algorithm makes
  * (an occluded light ray stops at its first occluder in primitive order,
  * MyApplication.cs:373-378), whatever the kernels actually evaluate; like the times they are
- * meaningful only for calls made while profiling is enabled (without it a light ray stops at
+ * collected only by calls made in profiling mode 1 (otherwise the traversal kernels keep no
+ * work counters — the fields then hold the primary rays' share only — and a light ray stops at
  * whichever occluder it meets first, which changes no pixel but leaves "first in primitive
  * order" unknown).  The ray counts are always exact.
  * Times are milliseconds of the last call, measured with HIP events on the stream the
- * kernels ran on and only while profiling is enabled (rt_set_profiling): kernel_ms spans
+ * kernels ran on and only in profiling modes 1 and 2 (rt_set_profiling): kernel_ms spans
  * the whole frame pipeline; primary_ms, trace_ms and shade_ms split it into the primary
  * kernel, the per-level ray traversal kernels and the per-level shading kernels.  With
  * several devices each is the maximum over the devices. */
@@ -300,8 +301,10 @@ int rt_debug_rays(rt_ctx *ctx, const rt_camera *camera, int width, int height, i
  * devices (needed to read the device-side counters). */
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 
-/* Enable (1) or disable (0) the exact Intersect-call counters and event timing for later
- * render calls on the context.  Off by default. */
+/* Profiling mode of later render calls on the context: 0 (default) none; 1 the exact
+ * Intersect-call and work counters and event timing (the counting instances of the kernels run:
+ * ~2 % slower, and a light ray looks at the whole scene); 2 event timing only (the kernels of
+ * mode 0 run, bracketed by events; rt_render does not overlap its copy with rendering). */
 int rt_set_profiling(rt_ctx *ctx, int enable);
 
 #ifdef __cplusplus

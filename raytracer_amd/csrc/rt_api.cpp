@@ -91,7 +91,7 @@ struct rt_ctx {
     std::vector<DeviceState> dev;
     std::string error;
     bool have_scene = false;
-    bool profiling = false;
+    int profiling = 0;             // RT_PROFILE_*: 0 off, 1 counters and event timing, 2 event timing only
     int num_prims = 0, num_lights = 0, ns = 0, np = 0, nt = 0;
     uint32_t textures_used = 0;    // bit i: some primitive names texture slot i
     uint32_t textures_loaded = 0;  // bit i: slot i holds an image
@@ -655,7 +655,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     const int shared_walk = d.scene.nl >= 4 ? 3 : 2;
     d.frame.first_lights = tiles0 >= RT_CHAIN_BOUND_TILES_PER_WORKGROUP * d.resident_blocks ? shared_walk : 0;
     if (first_env) d.frame.first_lights = std::max(0, std::min(atoi(first_env), shared_walk));
-    d.frame.any_hit = ctx->profiling ? 0 : 1;
+    d.frame.any_hit = ctx->profiling == 1 ? 0 : 1;   // the counting kernels walk everything
     // On still smaller frames (measured: below ~6 tiles per resident workgroup; 4K / 8 GPUs has 4)
     // it pays to reserve the oldest workgroup of every compute unit for the chain: a SIMD issues
     // for its oldest waves first, so a chain tile in a young workgroup crawls while its elders
@@ -668,7 +668,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     const DevFrame &f = d.frame;
     if (part > 0) HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, FRAME_CONTROL_BYTES - RT_COUNTER_SLOTS * sizeof(DevCounters), stream));
     else HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, FRAME_CONTROL_BYTES, stream));
-    d.timed = ctx->profiling;
+    d.timed = ctx->profiling != 0;
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
     const int blocks = std::max(1, std::min({(P + 255) / 256, d.num_cus * 8, RT_COUNTER_SLOTS}));
     // k_primary's workgroups claim their 32x32-pixel tiles dynamically: as many workgroups as are
@@ -799,7 +799,8 @@ const char *rt_last_error(const rt_ctx *ctx)
 int rt_set_profiling(rt_ctx *ctx, int enable)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
-    ctx->profiling = enable != 0;
+    if (enable < 0 || enable > 2) return fail(ctx, RT_ERR_INVALID_ARG, "profiling mode %d is none of 0, 1, 2", enable);
+    ctx->profiling = enable;
     return RT_OK;
 }
 

@@ -1428,7 +1428,9 @@ struct Taker {
 // RESERVE: the chain tiles are kept to the oldest workgroups of the compute units (see the claim
 // loop); an instance of its own, because the bookkeeping costs the plain instance ~1.5 % of a
 // large frame in register pressure.
-template <int LCMAX, bool MULTI, bool RESERVE>
+// COUNT: the work counters of rt_stats are kept (profiling); without them the compiler drops
+// the per-lane sums and the per-light prefix lookups they are made of.
+template <int LCMAX, bool MULTI, bool RESERVE, bool COUNT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 k_trace_levels(DevScene s, DevFrame f)
 {
@@ -1573,7 +1575,7 @@ k_trace_levels(DevScene s, DevFrame f)
     PHASE_MARK(pc, 0)
     flush_counters(f, cnt_sh, pc.clk);
 #else
-    flush_test_counts(f, cnt_sh, tc);
+    if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
 #endif
 }
 
@@ -1885,14 +1887,16 @@ void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting,
 }
 
 typedef void (*trace_levels_kernel)(DevScene, DevFrame);
-static trace_levels_kernel trace_levels_for(const DevScene &s, bool reserve = false)
+template <bool RESERVE, bool COUNT>
+static trace_levels_kernel trace_levels_pick(const DevScene &s)
 {
-    if (reserve) {
-        if (multi_chunk(s)) return s.nl >= 4 ? k_trace_levels<4, true, true> : k_trace_levels<2, true, true>;
-        return s.nl >= 4 ? k_trace_levels<4, false, true> : k_trace_levels<2, false, true>;
-    }
-    if (multi_chunk(s)) return s.nl >= 4 ? k_trace_levels<4, true, false> : k_trace_levels<2, true, false>;
-    return s.nl >= 4 ? k_trace_levels<4, false, false> : k_trace_levels<2, false, false>;
+    if (multi_chunk(s)) return s.nl >= 4 ? k_trace_levels<4, true, RESERVE, COUNT> : k_trace_levels<2, true, RESERVE, COUNT>;
+    return s.nl >= 4 ? k_trace_levels<4, false, RESERVE, COUNT> : k_trace_levels<2, false, RESERVE, COUNT>;
+}
+static trace_levels_kernel trace_levels_for(const DevScene &s, bool reserve = false, bool count = true)
+{
+    if (reserve) return count ? trace_levels_pick<true, true>(s) : trace_levels_pick<true, false>(s);
+    return count ? trace_levels_pick<false, true>(s) : trace_levels_pick<false, false>(s);
 }
 
 int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus)
@@ -1908,7 +1912,7 @@ int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus)
 
 void rtk_trace_levels(const DevScene &s, const DevFrame &f, int grid_blocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(trace_levels_for(s, f.chain_policy != 0), dim3(grid_blocks), dim3(256), 0, stream, s, f);
+    hipLaunchKernelGGL(trace_levels_for(s, f.chain_policy != 0, f.any_hit == 0), dim3(grid_blocks), dim3(256), 0, stream, s, f);
 }
 
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,

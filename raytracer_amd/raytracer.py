@@ -86,8 +86,9 @@ class RenderContext:
         self._check(self._lib.rt_unpin_pixels(self._ctx))
         self._pinned_keepalive = None
 
-    def set_profiling(self, enable: bool) -> None:
-        self._check(self._lib.rt_set_profiling(self._ctx, 1 if enable else 0))
+    def set_profiling(self, enable) -> None:
+        """rt_set_profiling: False / 0 off, True / 1 counters and kernel timing, 2 kernel timing only."""
+        self._check(self._lib.rt_set_profiling(self._ctx, int(enable)))
 
     def render(self, camera: Camera, width: int, height: int,
                max_depth: int = abi.RT_REFERENCE_MAX_DEPTH,

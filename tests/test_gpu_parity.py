@@ -408,6 +408,35 @@ def test_framebuffer_at_any_alignment(size, offset):
     assert np.all(guard[:offset] == 0x5A5A5A5A) and np.all(guard[offset + w * h:] == 0x5A5A5A5A)
 
 
+def test_profiling_modes(oracle):
+    """Mode 0: no counters, no times.  Mode 2: the same kernels bracketed by events.  Mode 1: the
+    counting kernels, whose Intersect-call counts equal the restatement's.  Same pixels in all."""
+    fs = scene_1k().flatten()
+    cam, (w, h), depth = Camera(), (320, 200), 3
+    ref, cnt = oracle.render(fs, cam, w, h, max_depth=depth)
+    with RenderContext() as c:
+        c.set_scene(fs)
+        plain = c.render(cam, w, h, depth)
+        st0 = c.stats()
+        c.set_profiling(2)
+        timed = c.render(cam, w, h, depth)
+        st2 = c.stats()
+        c.set_profiling(1)
+        counted = c.render(cam, w, h, depth)
+        st1 = c.stats()
+        with pytest.raises(RtError):
+            c.set_profiling(3)
+    assert np.array_equal(plain, ref) and np.array_equal(timed, ref) and np.array_equal(counted, ref)
+    for st in (st0, st1, st2):   # the ray counts never depend on the mode
+        for k in ("rays_primary", "rays_shadow", "rays_secondary", "shaded_hits"):
+            assert st[k] == cnt[k], k
+    assert st0["kernel_ms"] == 0.0 and st2["kernel_ms"] > 0.0 and st2["trace_ms"] > 0.0 and st1["kernel_ms"] > 0.0
+    assert st1["sphere_tests"] == cnt["sphere_tests"] and st1["plane_tests"] == cnt["plane_tests"]
+    # without the counting kernels only the primary rays' share is known
+    ns = int((fs.prim_types == 0).sum())
+    assert st0["sphere_tests"] == st2["sphere_tests"] == w * h * ns
+
+
 def test_pipeline_slots_alternate_streams_on_one_context(ctx, oracle):
     """FramePipeline on one rank: consecutive frames go through two slots (two streams, two
     frame buffers) of ONE render context; each slot's stream waits for the previous frame's
