@@ -691,7 +691,10 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
         rtk_trace_levels(d.scene, f, std::max(1, std::min({2 * tiles0, d.resident_blocks, RT_COUNTER_SLOTS})), stream);
     }
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[2], stream));
-    for (int k = max_depth; k >= 0; k--) rtk_shade_level(d.scene, f, k, dev_pixels, blocks, stream);
+    // The shading kernels are bandwidth-bound and keep no counters: 32 workgroups per compute unit
+    // (measured at 3840x2160: 0.128 ms against 0.145 with 8 and 0.143 with 128).
+    const int shade_blocks = std::max(1, std::min((P + 255) / 256, d.num_cus * 32));
+    for (int k = max_depth; k >= 0; k--) rtk_shade_level(d.scene, f, k, dev_pixels, shade_blocks, stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[3], stream));
     if (part >= 0)
         HIP_TRY(ctx, hipMemcpyAsync(d.outcome_snap + (size_t)part * FRAME_OUTCOME_BYTES, f.sched, FRAME_OUTCOME_BYTES,
