@@ -68,11 +68,11 @@ def pmc_traffic() -> tuple:
     """HBM bytes per launch of the traversal kernel on this workload, from the committed
     rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot be collected from inside this
     process); (None, reason) when the summary is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_v15_trace_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_v16_trace_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        return int(d["traffic_bytes_per_launch"]), "profiles/r01_v15_trace_traffic.json (rocprofv3 --pmc, one GPU)"
+        return int(d["traffic_bytes_per_launch"]), "profiles/r01_v16_trace_traffic.json (rocprofv3 --pmc, one GPU)"
     except (OSError, KeyError, ValueError):
         return None, "no PMC summary committed"
 
