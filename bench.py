@@ -3,28 +3,39 @@
 
 One process per GPU (`python bench.py` for one GPU; the driver launches N ranks through
 torch.distributed.run).  A step is one frame: every rank renders its rows of the SAME
-3840x2160 frame (every N-th band of 16 rows: rt_render_bands_device; scene and scratch
-resident in HBM), then the blocks are gathered on rank 0 with one RCCL collective
-(torch.distributed backend "nccl") and put back in row order.  Total work is fixed as N
-grows: strong scaling.  The timed frames run without the library's counters; the ray counts
-and per-kernel HIP-event times come from one more frame rendered afterwards with them on.
+frame (every N-th band of 16 rows: rt_render_bands_device; scene and scratch resident in HBM),
+then the blocks are gathered on rank 0 with one RCCL collective (torch.distributed backend
+"nccl") and put back in row order.  Total work is fixed as N grows: strong scaling.  The timed
+frames run without the library's counters; the ray counts and per-kernel HIP-event times come
+from a few more frames rendered afterwards.  After the timed loop every rank asks the library
+whether the device gave up on any frame (rt_frame_status) and the run fails if one did.
 
 Printed by rank 0: one JSON line with
   value        whole-job Mrays/s = (primary + shadow + used reflection rays per frame,
-               de-duplicated as include/rt_hip.h defines them) / seconds per frame
-  roofline     the ray-traversal kernel (k_trace_levels, every level): algorithmic FLOP of
-               the Intersect calls the reference algorithm makes (25 per ray-sphere test,
-               13 per ray-plane, 51 per ray-triangle) / its HIP-event time in the last
-               timed frame, against the 157.3 TFLOP/s vector-FP32 peak.  The kernels skip
-               groups of spheres whose bounding ball no ray of a wave can meet, so the
-               algorithmic rate can exceed the peak; "executed" gives the FLOP of the filter
-               evaluations and exact candidates the kernel really ran over the same time.
-  cpu_baseline the CPU restatement (oracle/, literal per-light recursion like the
-               reference, all host threads) timed on the same frame
+               de-duplicated as include/rt_hip.h defines them) / seconds per frame; the timed
+               step ends with the frame in rank 0's DEVICE memory
+  roofline     the ray-traversal kernel (k_trace_levels, every level in one launch): the FLOP it
+               EXECUTED per launch (filter evaluations of rays against spheres and bounding
+               balls, per-origin terms, exact Intersect of the candidates, plane and triangle
+               tests; from the library's work counters) / its HIP-event time, against the
+               157.3 TFLOP/s vector-FP32 peak.  `algorithmic_tflops` prices the same launch at
+               the Intersect calls the reference's brute-force algorithm makes (25 FLOP per
+               ray-sphere test ...); the kernel culls most of them, so that figure is a
+               speed-up over brute force (`algorithmic_speedup`), not a hardware rate.
+               `valu_issue_util`: VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU,
+               committed under profiles/) x 2 cycles / (SIMD-cycles of the launch).
+  handoff      what the host pays beyond `value`: N = 1, rt_render into pageable host memory
+               (Surface.pixels) and into page-locked memory; N > 1, kernel / gather / device-to-
+               host times of a frame
+  cpu_baseline the CPU restatement (oracle/) timed on the host cores, on a stated sample
+
+`--config c5` runs the 64k-sphere / 16-light / 8-bounce stress scene at 1920x1080 instead.
+Rehearsal on a box with fewer GPUs than ranks: RT_BENCH_BACKEND=gloo RT_BENCH_ONE_GPU=1.
 """
 from __future__ import annotations
 
 import argparse
+import faulthandler
 import json
 import os
 import sys
@@ -36,79 +47,102 @@ import torch  # noqa: F401  (imported before librt_hip.so so both share one HIP 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from raytracer_amd import Camera, RenderContext, scene_1k  # noqa: E402
+from raytracer_amd import Camera, RenderContext, RtError, scene_1k, scene_64k  # noqa: E402
 from raytracer_amd.distributed import FramePipeline, render_block  # noqa: E402
 
-WIDTH, HEIGHT, MAX_DEPTH = 3840, 2160, 4
-PEAK_FP32_TFLOPS = 157.3
+PEAK_FP32_TFLOPS = 157.3          # 256 CUs x 4 SIMDs x 64 lanes x 2 FLOP / 2 cycles x 2.4 GHz
+SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 2.0
 FLOP_SPHERE, FLOP_PLANE, FLOP_TRIANGLE, FLOP_LIGHT_SHADE = 25.0, 13.0, 51.0, 80.0
 
+CONFIGS = {
+    # BASELINE.json configs[2]: the configuration the headline metric is quoted on.
+    "c3": dict(width=3840, height=2160, max_depth=4, scene=scene_1k, cpu_row_step=1, cpu_mode="literal",
+               workload="synthetic 1k-sphere scene (1000 spheres + 6 planes, 2 lights), 3840x2160, 4 mirror bounces",
+               pmc="r02_c3_trace_pmc.json"),
+    # BASELINE.json configs[4]: divergence / occupancy stress.
+    "c5": dict(width=1920, height=1080, max_depth=8, scene=scene_64k, cpu_row_step=54, cpu_mode="memoised",
+               workload="synthetic 64k-sphere scene (65536 spheres + 6 planes, 16 lights), 1920x1080, 8 mirror bounces",
+               pmc="r02_c5_trace_pmc.json"),
+}
 
-def cpu_baseline(flat, cam, row_step: int = 1) -> dict:
-    """CPU path next to the GPU number: literal mode (reflection re-traced per light, as
-    objects.cs:80-88 does), rows spread over the host threads like Parallel.For."""
+
+def cpu_baseline(cfg, flat, cam) -> dict:
+    """CPU path next to the GPU number, rows spread over the host threads like Parallel.For.
+    Literal mode re-traces the reflection per light as objects.cs:80-88 does; with 16 lights and
+    8 bounces that is 16^8 re-traces, so that scene is timed in memoised mode (same pixels)."""
     from oracle import oracle as O  # checker / baseline only; never on the product path
     O.build()
+    w, h, depth, step = cfg["width"], cfg["height"], cfg["max_depth"], cfg["cpu_row_step"]
+    mode = O.MODE_LITERAL if cfg["cpu_mode"] == "literal" else O.MODE_MEMOISED
     threads = O.num_threads()
     t0 = time.perf_counter()
-    O.render(flat, cam, WIDTH, HEIGHT, max_depth=MAX_DEPTH, mode=O.MODE_LITERAL, row_step=row_step)
+    _, cnt = O.render(flat, cam, w, h, max_depth=depth, mode=mode, row_step=step)
     dt = time.perf_counter() - t0
-    # Ray count of the same rows, de-duplicated like the GPU's (memoised mode, not timed).
-    _, cnt = O.render(flat, cam, WIDTH, HEIGHT, max_depth=MAX_DEPTH, mode=O.MODE_MEMOISED,
-                      row_step=row_step)
+    if mode != O.MODE_MEMOISED:   # ray count of the same rows, de-duplicated like the GPU's (not timed)
+        _, cnt = O.render(flat, cam, w, h, max_depth=depth, mode=O.MODE_MEMOISED, row_step=step)
     rays = cnt["rays_primary"] + cnt["rays_shadow"] + cnt["rays_secondary"]
+    how = "literal per-light recursion" if mode == O.MODE_LITERAL else "memoised recursion (one trace per level)"
     return {
         "value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "sample": f"{len(range(0, HEIGHT, row_step))} of the {HEIGHT} rows (every "
-                  f"{row_step}) of the {WIDTH}x{HEIGHT} frame, literal per-light recursion, {dt:.1f} s",
+        "sample": f"{len(range(0, h, step))} of the {h} rows (every {step}) of the {w}x{h} frame, {how}, {dt:.1f} s",
     }
 
 
-def pmc_traffic() -> tuple:
-    """HBM bytes per launch of the traversal kernel on this workload, from the committed
-    rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot be collected from inside this
-    process); (None, reason) when the summary is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_v16_trace_traffic.json")
+def pmc_summary(name: str) -> dict:
+    """Per-launch counters of the traversal kernel on this workload from the committed rocprofv3
+    PMC passes (they cannot be collected from inside this process); {} when missing."""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
-        return int(d["traffic_bytes_per_launch"]), "profiles/r01_v16_trace_traffic.json (rocprofv3 --pmc, one GPU)"
-    except (OSError, KeyError, ValueError):
-        return None, "no PMC summary committed"
+        d["source"] = f"profiles/{name} (rocprofv3 --pmc, separate passes, one GPU)"
+        return d
+    except (OSError, ValueError):
+        return {}
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    W, H, DEPTH = cfg["width"], cfg["height"], cfg["max_depth"]
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
-    torch.cuda.set_device(local_rank)
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("RT_BENCH_ONE_GPU") else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
+        # A rank that never arrives must end the job with a traceback, not hold the node.
+        faulthandler.dump_traceback_later(int(os.environ.get("RT_BENCH_WATCHDOG_S", "300")), exit=True)
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        nranks = dist.get_world_size()
     else:
         dist = None
+        nranks = 1
 
     cam = Camera()
-    flat = scene_1k().flatten()
-    ctx = RenderContext([local_rank])
+    flat = cfg["scene"]().flatten()
+    ctx = RenderContext([dev_index])
     ctx.set_scene(flat)
     # Several ranks: two frames in flight, so that a frame's gather (and rank 0's row
     # permutation) runs while the next frame renders.
-    pipeline = FramePipeline(WIDTH, HEIGHT, rank, world, torch.device("cuda", local_rank),
-                             depth=2 if world > 1 else 1)
+    pipeline = FramePipeline(W, H, rank, world, device, depth=2 if world > 1 else 1)
 
     def step() -> None:
-        pipeline.render_frame(ctx, cam, MAX_DEPTH)
+        pipeline.render_frame(ctx, cam, DEPTH)
 
     def fence() -> None:
         torch.cuda.synchronize()
@@ -125,103 +159,172 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
 
+    # Did the device finish every frame it was given?  (A stalled level schedule leaves a frame
+    # incomplete; its time must not be reported.)  Every rank checks, every rank learns the result.
+    stalled = 0.0
+    try:
+        ctx.frame_status()
+    except RtError as e:
+        print(f"[bench rank {rank}] {e}", file=sys.stderr, flush=True)
+        stalled = 1.0
+
     # Kernel durations of the SAME kernels the timed loop ran: a few more frames bracketed by HIP
     # events on the stream (profiling mode 2), averaged.
     ctx.set_profiling(2)
     ev = {"trace_ms": 0.0, "kernel_ms": 0.0, "primary_ms": 0.0, "shade_ms": 0.0}
     EVENT_FRAMES = 5
     for _ in range(EVENT_FRAMES):
-        render_block(ctx, cam, WIDTH, HEIGHT, MAX_DEPTH, pipeline.begin())
+        render_block(ctx, cam, W, H, DEPTH, pipeline.begin())
         timed = ctx.stats()  # synchronises
         for k in ev:
             ev[k] += timed[k] / EVENT_FRAMES
     # One more frame with the device-side work counters on (profiling mode 1: the counting
-    # instances of the kernels, ~2 % slower; only their counts are used).
+    # instances of the kernels, a few per cent slower; only their counts are used).
     ctx.set_profiling(1)
-    render_block(ctx, cam, WIDTH, HEIGHT, MAX_DEPTH, pipeline.begin())
+    render_block(ctx, cam, W, H, DEPTH, pipeline.begin())
     st = ctx.stats()
+    ctx.set_profiling(0)
+
+    # Beyond the timed step: N > 1, the gather and the copy of the gathered frame to the host, each
+    # timed on its own; N = 1 below (rank 0 only).
+    handoff = {}
+    if world > 1:
+        g = pipeline.begin()
+        render_block(ctx, cam, W, H, DEPTH, g)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        with torch.cuda.stream(g.stream):
+            e0.record()
+        pipeline.finish(g)
+        host = torch.empty((H, W), dtype=torch.int32, pin_memory=True) if rank == 0 else None
+        with torch.cuda.stream(g.stream):
+            e1.record()
+            if rank == 0:
+                host.copy_(g.frame, non_blocking=True)
+            e2.record()
+        g.stream.synchronize()
+        handoff = {"kernel_ms": round(ev["kernel_ms"], 4), "gather_ms": round(e0.elapsed_time(e1), 4),
+                   "d2h_ms": round(e1.elapsed_time(e2), 4) if rank == 0 else None,
+                   "note": "rank 0; one frame after the timed loop: this rank's kernels (HIP events), the gather "
+                           f"({backend}) with rank 0's row permutation, the copy of the whole frame into page-locked "
+                           "host memory; in the timed loop the gather overlaps the next frame's kernels"}
+
     keys = ("rays_primary", "rays_shadow", "rays_secondary", "shaded_hits", "sphere_tests",
             "plane_tests", "triangle_tests", "filter_ray_tests", "filter_origin_terms", "exact_candidates",
             "primary_filter_ray_tests", "primary_exact_candidates")
     totals = torch.tensor([float(st[k]) for k in keys], dtype=torch.float64, device="cuda")
-    times = torch.tensor([elapsed, ev["trace_ms"], ev["kernel_ms"], ev["primary_ms"], ev["shade_ms"]],
+    times = torch.tensor([elapsed, ev["trace_ms"], ev["kernel_ms"], ev["primary_ms"], ev["shade_ms"], stalled],
                          dtype=torch.float64, device="cuda")
     if dist is not None:
+        if backend != "nccl":   # (host tensors: see FrameGatherer._gather_through_host)
+            totals, times = totals.cpu(), times.cpu()
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     tot = dict(zip(keys, totals.tolist()))
-    elapsed, trace_ms, kernel_ms, primary_ms, shade_ms = times.tolist()
+    elapsed, trace_ms, kernel_ms, primary_ms, shade_ms, stalled = times.tolist()
+    if stalled:
+        ctx.close()
+        raise SystemExit("bench: the device gave up on a frame of the timed loop (see stderr); no result")
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         rays = tot["rays_primary"] + tot["rays_shadow"] + tot["rays_secondary"]
         ns, npl, nt = (int((flat.prim_types == t).sum()) for t in (0, 1, 2))
-        # Tests made by the traversal kernels = all tests minus the primary rays' share.
+        # Tests made by the traversal kernel = all tests minus the primary rays' share.
         tr_s = tot["sphere_tests"] - tot["rays_primary"] * ns
         tr_p = tot["plane_tests"] - tot["rays_primary"] * npl
         tr_t = tot["triangle_tests"] - tot["rays_primary"] * nt
-        trace_flop = FLOP_SPHERE * tr_s + FLOP_PLANE * tr_p + FLOP_TRIANGLE * tr_t
-        frame_flop = (FLOP_SPHERE * tot["sphere_tests"] + FLOP_PLANE * tot["plane_tests"] +
-                      FLOP_TRIANGLE * tot["triangle_tests"] +
-                      FLOP_LIGHT_SHADE * tot["shaded_hits"] * flat.num_lights)
-        # Per-GPU rate of the dominant kernel: each rank traced 1/world of the FLOP.
-        achieved = trace_flop / world / (trace_ms * 1e-3) / 1e12 if trace_ms > 0 else 0.0
-        # What the trace kernel executed: filter evaluations (4 FMA per ray and entry, 3 FMA +
-        # 1 subtraction per origin and entry), the exact Intersect of the candidates (36 FLOP
-        # per ray; a record has rays_per_record rays on average) and the plane / triangle tests.
+        algorithmic_flop = FLOP_SPHERE * tr_s + FLOP_PLANE * tr_p + FLOP_TRIANGLE * tr_t
+        # What the traversal kernel executed: filter evaluations (4 FMA per ray and entry, 3 FMA +
+        # 1 subtraction per origin and entry), the exact Intersect of the candidates (36 FLOP per
+        # ray; a record has rays_per_record rays on average) and the plane / triangle tests.
         tr_filter_rays = tot["filter_ray_tests"] - tot["primary_filter_ray_tests"]
         tr_candidates = tot["exact_candidates"] - tot["primary_exact_candidates"]
         rays_per_record = (tot["rays_shadow"] + tot["rays_secondary"]) / max(tot["shaded_hits"], 1.0)
         executed_flop = (8.0 * tr_filter_rays + 7.0 * tot["filter_origin_terms"] +
                          (FLOP_SPHERE + 11.0) * rays_per_record * tr_candidates +
                          FLOP_PLANE * tr_p + FLOP_TRIANGLE * tr_t)
-        executed = executed_flop / world / (trace_ms * 1e-3) / 1e12 if trace_ms > 0 else 0.0
+        trace_s = trace_ms * 1e-3
+        # Per-GPU rate of the dominant kernel: each rank traced 1/world of the FLOP.
+        executed = executed_flop / world / trace_s / 1e12 if trace_s > 0 else 0.0
+        algorithmic = algorithmic_flop / world / trace_s / 1e12 if trace_s > 0 else 0.0
+        pmc = pmc_summary(cfg["pmc"]) if world == 1 else {}
+        valu_insts = pmc.get("sq_insts_valu_per_launch")
         line = {
-            "metric": "Mrays/sec (primary+secondary) at 3840x2160",
+            "metric": "Mrays/sec (primary+secondary) at 3840x2160" if args.config == "c3"
+                      else f"Mrays/sec (primary+secondary) at {W}x{H}",
             "value": round(rays / (ms_per_step * 1e-3) / 1e6, 2),
             "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "nranks": nranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "synthetic 1k-sphere scene (1000 spheres + 6 planes, 2 lights), "
-                            "3840x2160, 4 mirror bounces",
-                "width": WIDTH, "height": HEIGHT, "max_depth": MAX_DEPTH,
+                "workload": cfg["workload"],
+                "width": W, "height": H, "max_depth": DEPTH,
                 "spheres": ns, "planes": npl, "lights": flat.num_lights,
                 "partition": ("whole frame on one GPU" if world == 1 else
-                              f"every {world}th band of 16 rows per rank, RCCL gather to rank 0, "
+                              f"every {world}th band of 16 rows per rank, {backend} gather to rank 0, "
                               "two frames in flight (a frame's gather overlaps the next frame's rendering)"),
-                "rays_per_frame": int(rays),
-                "exact_candidates_rank0": int(st["exact_candidates"]),
+                "rays_counted": "primary + shadow + secondary (one shadow ray per shaded hit and light, one "
+                                "secondary ray per shaded specular hit below the depth bound, de-duplicated per level)",
+                "rays_per_frame": {"primary": int(tot["rays_primary"]), "shadow": int(tot["rays_shadow"]),
+                                   "secondary": int(tot["rays_secondary"]), "total": int(rays)},
+                "counts_source": "one frame after the timed loop rendered with the library's work counters on "
+                                 "(rt_set_profiling 1); kernel times: five frames with HIP events (mode 2)",
+                "timed_step_ends": "frame in device memory of rank 0 (see handoff for the host copy)",
             },
             "roofline": {
                 "bound": "valu-fp32", "kernel": "k_trace_levels (every level of the frame in one launch)",
-                "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                "traffic": pmc_traffic()[0] if world == 1 else None, "traffic_source": pmc_traffic()[1],
-                "algorithmic_flop_per_launch": trace_flop / world,
+                "achieved": round(executed, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(executed / PEAK_FP32_TFLOPS, 4),
+                "executed_flop_per_launch": executed_flop / world,
                 "kernel_ms": round(trace_ms, 4),
                 "kernel_ms_source": f"HIP events on the kernels' stream, mean of {EVENT_FRAMES} frames after the timed "
                                     "loop, same kernels as the timed loop",
-                "executed": {"flop_per_launch": executed_flop / world, "tflops": round(executed, 3),
-                             "frac": round(executed / PEAK_FP32_TFLOPS, 4),
-                             "filter_ray_tests": int(tr_filter_rays),
-                             "algorithmic_sphere_tests": int(tr_s),
-                             "note": "bounding-ball culling skips most of the algorithmic sphere tests"},
-                "frame": {"flop": frame_flop, "pipeline_ms": round(kernel_ms, 4),
-                          "primary_ms": round(primary_ms, 4), "shade_ms": round(shade_ms, 4),
-                          "tflops": round(frame_flop / world / (kernel_ms * 1e-3) / 1e12, 3)
-                          if kernel_ms > 0 else 0.0},
+                "valu_issue_util": (round(valu_insts * VALU_ISSUE_CYCLES / (trace_s * SIMDS * CLOCK_HZ), 4)
+                                    if valu_insts and trace_s > 0 else None),
+                "valu_insts_per_launch": valu_insts,
+                "traffic": pmc.get("traffic_bytes_per_launch"), "pmc_source": pmc.get("source"),
+                "algorithmic_tflops": round(algorithmic, 3),
+                "algorithmic_flop_per_launch": algorithmic_flop / world,
+                "algorithmic_speedup": round(algorithmic_flop / executed_flop, 3) if executed_flop > 0 else None,
+                "filter_ray_tests": int(tr_filter_rays), "algorithmic_sphere_tests": int(tr_s),
+                "frame": {"pipeline_ms": round(kernel_ms, 4), "primary_ms": round(primary_ms, 4),
+                          "shade_ms": round(shade_ms, 4)},
             },
         }
+        if world == 1:
+            # Render() ends with the pixels in host memory (MyApplication.cs:420): rt_render into a
+            # pageable array, and into a page-locked one where the system allows registering it.
+            out = np.empty((H, W), dtype=np.int32)
+            reps = 5 if args.config == "c3" else 2
+
+            def host_ms() -> float:
+                ctx.render(cam, W, H, DEPTH, out=out)
+                t = time.perf_counter()
+                for _ in range(reps):
+                    ctx.render(cam, W, H, DEPTH, out=out)
+                return (time.perf_counter() - t) / reps * 1e3
+
+            pageable = host_ms()
+            try:
+                ctx.pin_pixels(out)
+                pinned = round(host_ms(), 4)
+                ctx.unpin_pixels()
+            except RtError as e:
+                pinned = f"refused ({e.message.split(';')[0]})"
+            handoff = {"rt_render_pageable_ms": round(pageable, 4), "rt_render_pinned_ms": pinned,
+                       "note": "whole rt_render calls (kernels + copy into the caller's int[w*h]); a frame this size is "
+                               "rendered in row blocks whose copies overlap the next block's kernels"}
+        line["handoff"] = handoff
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(flat, cam)
+            line["cpu_baseline"] = cpu_baseline(cfg, flat, cam)
         print(json.dumps(line), flush=True)
 
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RT_API_VERSION 3
+#define RT_API_VERSION 4
 
 /* Primitive type codes — the reference's own flatten uses exactly these
  * (MyApplication.cs:161,166,173). */
@@ -53,7 +53,8 @@ typedef enum rt_status {
     RT_ERR_HIP            = -4,  /* a HIP runtime call failed (message has the detail)  */
     RT_ERR_NO_SCENE       = -5,  /* rt_render before rt_set_scene                        */
     RT_ERR_BAD_TEXTURE    = -6,  /* a primitive names a texture slot that is not loaded */
-    RT_ERR_LIMIT          = -7   /* request exceeds a fixed limit of an entry point     */
+    RT_ERR_LIMIT          = -7,  /* request exceeds a fixed limit of an entry point     */
+    RT_ERR_STALLED        = -8   /* the device gave up on a frame: its pixels are incomplete */
 } rt_status;
 
 /* Camera fields read by the render loop (MyApplication.cs:259-275: position,
@@ -270,6 +271,21 @@ int rt_render_bands_device(rt_ctx *ctx, const rt_camera *camera, int width, int 
 /* Rows of a height-row frame that fall to `part` of `parts` with bands of band_rows rows, or
  * RT_ERR_INVALID_ARG. */
 int rt_band_rows(int height, int band_rows, int part, int parts);
+
+/*
+ * Outcome of the frames enqueued with rt_render_rows_device / rt_render_bands_device since the
+ * last call: waits for the stream the last of them was enqueued on (which must still exist; the
+ * caller ordered the earlier ones before it, as calls on one context must not overlap) and
+ * returns RT_OK, or RT_ERR_STALLED when the device-side schedule of some frame gave up — a
+ * workgroup waited longer than the stall limit (one second; environment variable
+ * RT_HIP_STALL_MS) for the next level of reflection rays to open — in which case that frame's
+ * pixels are incomplete.  The report is consumed by the call.  rt_render makes the same check
+ * itself before it returns.  Costs nothing on the device: a stalled workgroup writes the
+ * report into page-locked host memory, nobody else writes anything.
+ * No counterpart in the reference (its loop cannot lose work; this one runs on a device-side
+ * schedule and returns before the frame is done).
+ */
+int rt_frame_status(rt_ctx *ctx);
 
 /*
  * Optional post-pass: the anti-aliasing filter the host's present path applies to the frame

@@ -25,6 +25,7 @@ STATUS_NAMES = {
     -5: "RT_ERR_NO_SCENE",
     -6: "RT_ERR_BAD_TEXTURE",
     -7: "RT_ERR_LIMIT",
+    -8: "RT_ERR_STALLED",
 }
 
 _f = C.POINTER(C.c_float)
@@ -123,6 +124,7 @@ EXPORTS = {
          C.c_void_p, C.c_void_p],
     ),
     "rt_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rt_frame_status": (C.c_int, [C.c_void_p]),
     "rt_debug_rays": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.POINTER(rt_debug_ray), C.POINTER(C.c_int)]),
     "rt_fxaa_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

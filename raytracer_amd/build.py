@@ -10,12 +10,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "librt_hip.so")
 SOURCES = ["rt_api.cpp", "rt_kernels.hip"]
-HEADERS = ["rt_device.h", "filter_asm.inc", os.path.join("..", "..", "include", "rt_hip.h")]
+# What each source includes (rt_kernels.hip takes minutes to compile: it must not be rebuilt
+# for a change of the public header, which it does not see).
+HEADERS = {
+    "rt_api.cpp": ["rt_device.h", os.path.join("..", "..", "include", "rt_hip.h")],
+    "rt_kernels.hip": ["rt_device.h", "filter_asm.inc"],
+}
 
 # -ffp-contract=off and IEEE divide/sqrt are part of the numerical contract of the
 # library (bit-level agreement with a strict-FP32 evaluation), not tuning knobs.
 FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
     # hipcc 7.2's SLP vectoriser crashes the gfx950 backend on the trace kernel
     # (RenameIndependentSubregs) and costs VGPRs elsewhere; packed math is written by hand
@@ -32,23 +37,47 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+OBJ_DIR = os.path.join(CSRC, "build")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    if not force and not needs_build():
+def _deps(source: str):
+    return [os.path.join(CSRC, f) for f in [source] + HEADERS[source]] + [os.path.abspath(__file__)]
+
+
+def needs_build() -> bool:
+    return any(_stale(LIB, _deps(s)) for s in SOURCES)
+
+
+def build_library(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB) -> str:
+    """One object per source (the kernels take minutes, the host side seconds), then the link.
+    ``extra_flags`` / ``out`` build a variant next to the in-tree library (its objects are not kept)."""
+    variant = bool(extra_flags) or out != LIB
+    if not force and not variant and not needs_build():
         return LIB
-    cmd = [hipcc(), *FLAGS, *extra_flags, "-x", "hip", *[os.path.join(CSRC, s) for s in SOURCES],
-           "-o", LIB]
+    obj_dir = OBJ_DIR + ("_variant" if variant else "")
+    os.makedirs(obj_dir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if not force and not variant and not _stale(obj, _deps(src)):
+            continue
+        cmd = [hipcc(), *FLAGS, *extra_flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB
+    return out
 
 
 TOOLS_DIR = os.path.join(os.path.dirname(HERE), "tools")

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -49,14 +50,28 @@ constexpr int RT_MAX_FRAME_PARTS = 8;
 constexpr int RT_BAND_ROWS = 16;
 constexpr long long RT_MIN_SPLIT_PIXELS = 3000000, RT_PART_PIXELS = 4000000;
 
-thread_local std::string g_create_error;
+// Messages live in fixed buffers so that reporting a failure can never itself fail.
+constexpr size_t RT_ERROR_CHARS = 512;
+thread_local char g_create_error[RT_ERROR_CHARS] = "";
+
+// Default patience of a workgroup of the level kernel that waits for a level to open, in
+// milliseconds (RT_HIP_STALL_MS overrides): far above anything a healthy frame shows (levels open
+// every few tens of microseconds), short enough that a lost frame is reported at once.
+constexpr unsigned RT_STALL_MS_DEFAULT = 1000;
 
 struct DeviceState {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {};  // begin, after primary, after trace, after shade, after gather copy
     int num_cus = 256;
-    int resident_blocks = 0;   // k_trace_levels workgroups resident at once (0: ask again, the scene changed)
+    // k_trace_levels workgroups resident at once, per instance [chain policy][counting] (0: ask
+    // again, the scene changed)
+    int resident_blocks[2][2] = {};
+    bool peer_to_root = true;  // this device can write the first device's memory (or is the first device)
+    // Outcome words the device writes only when a frame went wrong (DevFrame::status): page-locked,
+    // device-visible host memory, so that reading them costs a finished stream and nothing else.
+    int *status = nullptr;
+    hipStream_t last_stream = nullptr;   // the stream the last render call was enqueued on
 
     // scene
     DevScene scene{};
@@ -89,7 +104,7 @@ struct DeviceState {
 
 struct rt_ctx {
     std::vector<DeviceState> dev;
-    std::string error;
+    char error[RT_ERROR_CHARS] = "";
     bool have_scene = false;
     int profiling = 0;             // RT_PROFILE_*: 0 off, 1 counters and event timing, 2 event timing only
     int num_prims = 0, num_lights = 0, ns = 0, np = 0, nt = 0;
@@ -111,16 +126,29 @@ struct rt_ctx {
 
 namespace {
 
-int fail(rt_ctx *ctx, int code, const char *fmt, ...)
+int fail(rt_ctx *ctx, int code, const char *fmt, ...) noexcept
 {
-    char buf[512];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
+    vsnprintf(ctx ? ctx->error : g_create_error, RT_ERROR_CHARS, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->error = buf;
-    else g_create_error = buf;
     return code;
+}
+
+// Every entry point's body runs inside this: no C++ exception leaves the library (the host is
+// C#, C or ctypes: an exception unwinding into it is undefined behaviour).
+template <class Body>
+int guarded(rt_ctx *ctx, Body &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, RT_ERR_OUT_OF_MEMORY, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(ctx, RT_ERR_HIP, "unexpected exception: %s", e.what());
+    } catch (...) {
+        return fail(ctx, RT_ERR_HIP, "unexpected exception");
+    }
 }
 
 // memcpy with streaming stores: the destination (the caller's framebuffer) is written once and
@@ -445,7 +473,7 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     HIP_TRY(ctx, hipStreamSynchronize(d.stream));
     free_scene(d);
     DevScene &sc = d.scene;
-    d.resident_blocks = 0;
+    memset(d.resident_blocks, 0, sizeof d.resident_blocks);
     sc.ns_padded = (int)ps.sph.size();
     sc.ns = ps.class_prefix[3 * (size_t)n];
     sc.np = (int)ps.pl.size();
@@ -592,26 +620,17 @@ int check_render_args(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_d
     return RT_OK;
 }
 
-// After the device has finished a frame: did every workgroup of k_trace_levels see the
-// level it waited for?  (A set flag means the frame is incomplete.)
+// After the device has finished the frames enqueued so far (the caller has synchronised the
+// stream): did every workgroup of k_trace_levels see the level it waited for?  The device
+// reports a stall in d.status (host memory); the report is consumed here.
 int check_schedule(rt_ctx *ctx, DeviceState &d)
 {
     static_assert(RT_DEV_MAX_LEVELS >= RT_MAX_DEPTH + 2, "DevSched holds one entry per level");
-    if (!d.frame.sched) return RT_OK;
-    DevSched sc;
-    if (d.snap_parts > 0) {   // rendered in parts: every part left its outcome in host memory
-        for (int p = 0; p < d.snap_parts; p++) {
-            memcpy(&sc, d.outcome_snap + (size_t)p * FRAME_OUTCOME_BYTES, sizeof sc);
-            if (sc.error)
-                return fail(ctx, RT_ERR_HIP, "device %d: the level schedule stalled at level %d in part %d of the frame; "
-                            "the frame is incomplete", d.device, sc.open_level, p);
-        }
-        return RT_OK;
-    }
-    HIP_TRY(ctx, hipMemcpy(&sc, d.frame.sched, sizeof sc, hipMemcpyDeviceToHost));
     static const bool trace = getenv("RT_HIP_SCHED_TRACE") != nullptr;
-    if (trace) {
+    if (trace && d.frame.sched && d.snap_parts == 0) {
+        DevSched sc;
         std::vector<int> cnt(2 * (size_t)(d.last_depth + 2));
+        HIP_TRY(ctx, hipMemcpy(&sc, d.frame.sched, sizeof sc, hipMemcpyDeviceToHost));
         (void)hipMemcpy(cnt.data(), d.frame.cnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost);
         fprintf(stderr, "[rt_hip] trace launch: %.1f us;", (double)(sc.t_last - sc.t_first) * 0.01);
         for (int k = 1; k <= sc.open_level && k < RT_DEV_MAX_LEVELS; k++)
@@ -619,9 +638,31 @@ int check_schedule(rt_ctx *ctx, DeviceState &d)
                     cnt[2 * k], cnt[2 * k + 1]);
         fprintf(stderr, "; level 0: A %d B %d\n", cnt[0], cnt[1]);
     }
-    if (sc.error)
-        return fail(ctx, RT_ERR_HIP, "device %d: the level schedule stalled at level %d; the frame is incomplete",
-                    d.device, sc.open_level);
+    if (!d.status) return RT_OK;
+    volatile int *st = d.status;
+    if (st[0] != 0) {
+        const int level = st[1];
+        st[0] = 0;
+        st[1] = 0;
+        // What the schedule of the LAST frame looked like when it ended (the stalled frame's own, if
+        // the caller checks after every frame).
+        int claimed = -1, done = -1, records = -1;
+        if (d.frame.sched && level >= 1 && level < RT_DEV_MAX_LEVELS) {
+            DevSched sc;
+            int cnt[2 * RT_DEV_MAX_LEVELS];
+            if (hipMemcpy(&sc, d.frame.sched, sizeof sc, hipMemcpyDeviceToHost) == hipSuccess &&
+                hipMemcpy(cnt, d.frame.cnt, sizeof cnt, hipMemcpyDeviceToHost) == hipSuccess) {
+                claimed = sc.next_a[level - 1];
+                done = sc.done_a[level - 1];
+                records = cnt[2 * (level - 1)];
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        return fail(ctx, RT_ERR_STALLED, "device %d: the level schedule stalled (workgroups waited more than the stall "
+                    "limit for level %d to open; level %d: %d reflecting records, %d tile claims, %d tiles done); a frame "
+                    "rendered since the last check is incomplete", d.device, level, level - 1, records, claimed, done);
+    }
     return RT_OK;
 }
 
@@ -646,16 +687,24 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     if (rc != RT_OK) return rc;
     const DevCamera dc = make_camera(cam, w, h, rs);
     const int tiles0 = (P + 255) / 256;
-    if (d.resident_blocks <= 0) d.resident_blocks = rtk_trace_levels_resident_blocks(d.scene, d.num_cus);
+    const bool counting = ctx->profiling == 1;   // the counting kernels walk everything
+    // Workgroups of the level kernel that fit the device at once, for the instance a large frame
+    // launches (the policy decisions below are made against it) ...
+    auto resident = [&](bool reserve) {
+        int &r = d.resident_blocks[reserve][counting];
+        if (r <= 0) r = rtk_trace_levels_resident_blocks(d.scene, d.num_cus, reserve, counting);
+        return r;
+    };
+    const int resident_plain = resident(false);
     // The walk that carries a record's reflection ray is the one the next level waits for.
     // With plenty of tiles per resident workgroup the chain of levels hides behind the other
     // work and the ray shares its walk with the first lights (fewest instructions); on a small
     // frame the chain IS the frame time and the ray walks alone (shortest chain).
     static const char *first_env = getenv("RT_HIP_FIRST_LIGHTS");
     const int shared_walk = d.scene.nl >= 4 ? 3 : 2;
-    d.frame.first_lights = tiles0 >= RT_CHAIN_BOUND_TILES_PER_WORKGROUP * d.resident_blocks ? shared_walk : 0;
+    d.frame.first_lights = tiles0 >= RT_CHAIN_BOUND_TILES_PER_WORKGROUP * resident_plain ? shared_walk : 0;
     if (first_env) d.frame.first_lights = std::max(0, std::min(atoi(first_env), shared_walk));
-    d.frame.any_hit = ctx->profiling == 1 ? 0 : 1;   // the counting kernels walk everything
+    d.frame.any_hit = counting ? 0 : 1;
     // On still smaller frames (measured: below ~6 tiles per resident workgroup; 4K / 8 GPUs has 4)
     // it pays to reserve the oldest workgroup of every compute unit for the chain: a SIMD issues
     // for its oldest waves first, so a chain tile in a young workgroup crawls while its elders
@@ -663,8 +712,20 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // 0.571, hence the bound.  RT_HIP_CHAIN_POLICY=0/1 (tuning aid) overrides.
     static const char *policy_env = getenv("RT_HIP_CHAIN_POLICY");
     d.frame.chain_policy = policy_env ? (atoi(policy_env) != 0)
-                                      : tiles0 < RT_CHAIN_RESERVED_TILES_PER_WORKGROUP * d.resident_blocks;
+                                      : tiles0 < RT_CHAIN_RESERVED_TILES_PER_WORKGROUP * resident_plain;
     d.frame.num_cus = d.num_cus;
+    // ... and for the instance this frame launches (workgroups beyond what is resident at once
+    // would only start when the first ones leave, find nothing to claim and exit).
+    const int resident_blocks = resident(d.frame.chain_policy != 0);
+    d.frame.status = d.status;
+    const char *stall_env = getenv("RT_HIP_STALL_MS");   // (read at every call, like the knob below)
+    const long long stall_ms = stall_env && atoll(stall_env) > 0 ? atoll(stall_env) : (long long)RT_STALL_MS_DEFAULT;
+    d.frame.stall_ticks = (unsigned)std::min<long long>(stall_ms * 100000ll, 4000000000ll);   // 100 MHz wall clock
+    // RT_HIP_DEBUG_WITHHOLD_LEVEL (test knob, read at every call): the level whose first reflecting
+    // tile is never counted as done, which stalls the schedule there on purpose.
+    const char *withhold_env = getenv("RT_HIP_DEBUG_WITHHOLD_LEVEL");
+    d.frame.debug_withhold = withhold_env ? atoi(withhold_env) : -1;
+    d.last_stream = stream;
     const DevFrame &f = d.frame;
     if (part > 0) HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, FRAME_CONTROL_BYTES - RT_COUNTER_SLOTS * sizeof(DevCounters), stream));
     else HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, FRAME_CONTROL_BYTES, stream));
@@ -688,7 +749,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
         }
     } else {
         // Every level in one launch of resident workgroups (k_trace_levels).
-        rtk_trace_levels(d.scene, f, std::max(1, std::min({2 * tiles0, d.resident_blocks, RT_COUNTER_SLOTS})), stream);
+        rtk_trace_levels(d.scene, f, std::max(1, std::min({2 * tiles0, resident_blocks, RT_COUNTER_SLOTS})), stream);
     }
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[2], stream));
     // The shading kernels are bandwidth-bound and keep no counters: 32 workgroups per compute unit
@@ -720,6 +781,7 @@ int rt_create(rt_ctx **out, const int *device_ids, int n_devices)
 {
     if (!out) return fail(nullptr, RT_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
+    return guarded(nullptr, [&]() -> int {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device is visible");
@@ -746,6 +808,8 @@ int rt_create(rt_ctx **out, const int *device_ids, int n_devices)
         }
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipEventCreate(&d.ev[k]);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&d.status, 64, hipHostMallocMapped);
+        if (e == hipSuccess) memset(d.status, 0, 64);
         if (e != hipSuccess) {
             int rc = fail(nullptr, RT_ERR_HIP, "device %d setup failed: %s", d.device, hipGetErrorString(e));
             rt_destroy(ctx);
@@ -753,19 +817,29 @@ int rt_create(rt_ctx **out, const int *device_ids, int n_devices)
         }
         d.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    // Peer access towards the gathering device (the first one); the copies fall back to
-    // staging through the host when it is not available.
+    // Peer access towards the gathering device (the first one).  A device without it hands its
+    // rows over through page-locked host memory instead (rt_render).  RT_HIP_NO_PEER=1 (test knob)
+    // treats every other device as such.
+    const bool no_peer = getenv("RT_HIP_NO_PEER") != nullptr;
     for (size_t i = 1; i < ctx->dev.size(); i++) {
-        if (ctx->dev[i].device == ctx->dev[0].device) continue;
+        DeviceState &d = ctx->dev[i];
+        if (no_peer) {
+            d.peer_to_root = false;
+            continue;
+        }
+        if (d.device == ctx->dev[0].device) continue;
         int can = 0;
-        if (hipDeviceCanAccessPeer(&can, ctx->dev[i].device, ctx->dev[0].device) == hipSuccess && can) {
-            (void)hipSetDevice(ctx->dev[i].device);
-            hipError_t e = hipDeviceEnablePeerAccess(ctx->dev[0].device, 0);
-            if (e != hipSuccess) (void)hipGetLastError();  // already enabled is fine
+        d.peer_to_root = false;
+        if (hipDeviceCanAccessPeer(&can, d.device, ctx->dev[0].device) == hipSuccess && can) {
+            (void)hipSetDevice(d.device);
+            const hipError_t e = hipDeviceEnablePeerAccess(ctx->dev[0].device, 0);
+            d.peer_to_root = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+            if (e != hipSuccess) (void)hipGetLastError();
         }
     }
     *out = ctx;
     return RT_OK;
+    });
 }
 
 void rt_destroy(rt_ctx *ctx)
@@ -782,6 +856,7 @@ void rt_destroy(rt_ctx *ctx)
             if (d.ev[k]) (void)hipEventDestroy(d.ev[k]);
         if (d.stream) (void)hipStreamDestroy(d.stream);
         if (d.outcome_snap) (void)hipHostFree(d.outcome_snap);
+        if (d.status) (void)hipHostFree(d.status);
         if (d.bands) (void)hipFree(d.bands);
     }
     if (ctx->staging) (void)hipHostFree(ctx->staging);
@@ -796,7 +871,7 @@ void rt_destroy(rt_ctx *ctx)
 
 const char *rt_last_error(const rt_ctx *ctx)
 {
-    return ctx ? ctx->error.c_str() : g_create_error.c_str();
+    return ctx ? ctx->error : g_create_error;
 }
 
 int rt_set_profiling(rt_ctx *ctx, int enable)
@@ -820,13 +895,9 @@ int rt_set_scene(rt_ctx *ctx, const rt_scene *s)
         return fail(ctx, RT_ERR_INVALID_ARG, "a primitive array is NULL");
     if (s->num_lights > 0 && (!s->light_positions || !s->light_colors))
         return fail(ctx, RT_ERR_INVALID_ARG, "a light array is NULL");
+    return guarded(ctx, [&]() -> int {
     PackedScene ps;
-    int rc;
-    try {
-        rc = pack_scene(ctx, s, ps);
-    } catch (const std::bad_alloc &) {
-        return fail(ctx, RT_ERR_OUT_OF_MEMORY, "out of host memory while packing the scene");
-    }
+    int rc = pack_scene(ctx, s, ps);
     if (rc != RT_OK) return rc;
     ctx->have_scene = false;
     for (DeviceState &d : ctx->dev)
@@ -839,6 +910,7 @@ int rt_set_scene(rt_ctx *ctx, const rt_scene *s)
     ctx->textures_used = ps.textures_used;
     ctx->have_scene = true;
     return RT_OK;
+    });
 }
 
 int rt_set_texture(rt_ctx *ctx, int slot, const uint8_t *rgba8, int width, int height)
@@ -849,6 +921,7 @@ int rt_set_texture(rt_ctx *ctx, int slot, const uint8_t *rgba8, int width, int h
     if (!rgba8 || width <= 0 || height <= 0)
         return fail(ctx, RT_ERR_INVALID_ARG, "bad texture image (%p, %d x %d)", (const void *)rgba8, width, height);
     const size_t bytes = (size_t)width * (size_t)height * 4;
+    return guarded(ctx, [&]() -> int {
     for (DeviceState &d : ctx->dev) {
         HIP_TRY(ctx, hipSetDevice(d.device));
         HIP_TRY(ctx, hipStreamSynchronize(d.stream));
@@ -864,6 +937,7 @@ int rt_set_texture(rt_ctx *ctx, int slot, const uint8_t *rgba8, int width, int h
     }
     ctx->textures_loaded |= 1u << slot;
     return RT_OK;
+    });
 }
 
 int rt_render_rows_device(rt_ctx *ctx, const rt_camera *cam, int w, int h, int row_begin, int row_end,
@@ -874,6 +948,7 @@ int rt_render_rows_device(rt_ctx *ctx, const rt_camera *cam, int w, int h, int r
     if (row_begin < 0 || row_end > h || row_begin > row_end)
         return fail(ctx, RT_ERR_INVALID_ARG, "rows [%d, %d) outside [0, %d)", row_begin, row_end, h);
     if (!dev_pixels_out && row_end > row_begin) return fail(ctx, RT_ERR_INVALID_ARG, "dev_pixels_out is NULL");
+    return guarded(ctx, [&]() -> int {
     DeviceState &d = ctx->dev[0];
     ctx->last_was_rows_device = true;
     ctx->last_w = w;
@@ -882,6 +957,7 @@ int rt_render_rows_device(rt_ctx *ctx, const rt_camera *cam, int w, int h, int r
     for (size_t i = 1; i < ctx->dev.size(); i++) ctx->dev[i].last_P = 0;
     return enqueue_rows(ctx, d, cam, w, h, contiguous_rows(row_begin, row_end), max_depth, dev_pixels_out,
                         hip_stream ? static_cast<hipStream_t>(hip_stream) : d.stream);
+    });
 }
 
 int rt_band_rows(int height, int band_rows, int part, int parts)
@@ -899,6 +975,7 @@ int rt_render_bands_device(rt_ctx *ctx, const rt_camera *cam, int w, int h, int 
         return fail(ctx, RT_ERR_INVALID_ARG, "bad band partition: %d rows per band, part %d of %d", band_rows, part, parts);
     const RowSet rs{0, rows_of_part(h, band_rows, part, parts), band_rows, parts, part};
     if (!dev_pixels_out && rs.rows > 0) return fail(ctx, RT_ERR_INVALID_ARG, "dev_pixels_out is NULL");
+    return guarded(ctx, [&]() -> int {
     DeviceState &d = ctx->dev[0];
     ctx->last_was_rows_device = true;
     ctx->last_w = w;
@@ -907,13 +984,12 @@ int rt_render_bands_device(rt_ctx *ctx, const rt_camera *cam, int w, int h, int 
     for (size_t i = 1; i < ctx->dev.size(); i++) ctx->dev[i].last_P = 0;
     return enqueue_rows(ctx, d, cam, w, h, rs, max_depth, dev_pixels_out,
                         hip_stream ? static_cast<hipStream_t>(hip_stream) : d.stream);
+    });
 }
 
-int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, int32_t *pixels_out)
+static int render_to_host(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, int32_t *pixels_out)
 {
-    int rc = check_render_args(ctx, cam, w, h, max_depth);
-    if (rc != RT_OK) return rc;
-    if (!pixels_out) return fail(ctx, RT_ERR_INVALID_ARG, "pixels_out is NULL");
+    int rc = RT_OK;
     const long long total = (long long)w * (long long)h;
     if (total > INT32_MAX) return fail(ctx, RT_ERR_LIMIT, "frame of %lld pixels exceeds 2^31-1", total);
     const int G = (int)ctx->dev.size();
@@ -936,7 +1012,9 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, in
     }
     const bool direct = ctx->pinned && pixels_out >= ctx->pinned &&
                         (size_t)(pixels_out - ctx->pinned) + (size_t)total <= ctx->pinned_count;
-    if (!direct && (size_t)total > ctx->cap_staging) {
+    bool all_peers = true;
+    for (const DeviceState &d : ctx->dev) all_peers = all_peers && d.peer_to_root;
+    if ((!direct || !all_peers) && (size_t)total > ctx->cap_staging) {
         if (ctx->staging) (void)hipHostFree(ctx->staging);
         ctx->staging = nullptr;
         ctx->cap_staging = 0;
@@ -1015,7 +1093,9 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, in
     // (rows cost very different amounts; interleaved, every device gets its share of the
     // expensive ones), renders them stacked into a block of its own and writes them into device
     // 0's frame with ONE strided copy: source pitch = a band, destination pitch = G bands.
-    const bool interleaved = G > 1 && h >= 2 * G * RT_BAND_ROWS;
+    // (A device that cannot write device 0's memory takes a contiguous block, which it can hand
+    // over through host memory in one piece.)
+    const bool interleaved = G > 1 && h >= 2 * G * RT_BAND_ROWS && all_peers;
     if (interleaved) {
         const size_t band_px = (size_t)RT_BAND_ROWS * (size_t)w;
         const int nbands = (h + RT_BAND_ROWS - 1) / RT_BAND_ROWS;
@@ -1077,9 +1157,20 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, in
             const size_t bytes = (size_t)(y1 - y0) * (size_t)w * sizeof(int32_t);
             if (bytes == 0) continue;
             HIP_TRY(ctx, hipSetDevice(d.device));
-            HIP_TRY(ctx, hipMemcpyPeerAsync(root.out + (size_t)y0 * (size_t)w, root.device, d.out, d.device, bytes,
-                                            d.stream));
-            if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[4], d.stream));
+            if (d.peer_to_root) {
+                HIP_TRY(ctx, hipMemcpyPeerAsync(root.out + (size_t)y0 * (size_t)w, root.device, d.out, d.device, bytes,
+                                                d.stream));
+                if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[4], d.stream));
+            } else {
+                // No peer access: through the page-locked staging frame, then up to device 0 on its
+                // stream (the frame's final copy to the host follows on the same stream).
+                int32_t *via = ctx->staging + (size_t)y0 * (size_t)w;
+                HIP_TRY(ctx, hipMemcpyAsync(via, d.out, bytes, hipMemcpyDeviceToHost, d.stream));
+                HIP_TRY(ctx, hipEventRecord(d.ev[4], d.stream));
+                HIP_TRY(ctx, hipSetDevice(root.device));
+                HIP_TRY(ctx, hipStreamWaitEvent(root.stream, d.ev[4], 0));
+                HIP_TRY(ctx, hipMemcpyAsync(root.out + (size_t)y0 * (size_t)w, via, bytes, hipMemcpyHostToDevice, root.stream));
+            }
         }
     }
     ctx->gather_ms = 0.0;
@@ -1101,6 +1192,30 @@ int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, in
     return RT_OK;
 }
 
+int rt_render(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, int32_t *pixels_out)
+{
+    const int rc = check_render_args(ctx, cam, w, h, max_depth);
+    if (rc != RT_OK) return rc;
+    if (!pixels_out) return fail(ctx, RT_ERR_INVALID_ARG, "pixels_out is NULL");
+    return guarded(ctx, [&]() -> int { return render_to_host(ctx, cam, w, h, max_depth, pixels_out); });
+}
+
+int rt_frame_status(rt_ctx *ctx)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    return guarded(ctx, [&]() -> int {
+        int rc = RT_OK;
+        for (DeviceState &d : ctx->dev) {
+            if (!d.last_stream) continue;
+            HIP_TRY(ctx, hipSetDevice(d.device));
+            HIP_TRY(ctx, hipStreamSynchronize(d.last_stream));
+            const int r = check_schedule(ctx, d);
+            if (r != RT_OK) rc = r;
+        }
+        return rc;
+    });
+}
+
 int rt_debug_rays(rt_ctx *ctx, const rt_camera *cam, int w, int h, int row, int x_step, int max_rays,
                   rt_debug_ray *out, int *out_count)
 {
@@ -1110,11 +1225,12 @@ int rt_debug_rays(rt_ctx *ctx, const rt_camera *cam, int w, int h, int row, int 
     const int count = (w + x_step - 1) / x_step;
     if (count > max_rays) return fail(ctx, RT_ERR_LIMIT, "%d rays do not fit the caller's %d entries", count, max_rays);
     static_assert(sizeof(rt_debug_ray) == 14 * sizeof(float), "rt_debug_ray is 14 packed words");
+    return guarded(ctx, [&]() -> int {
     DeviceState &d = ctx->dev[0];
     HIP_TRY(ctx, hipSetDevice(d.device));
+    std::vector<float> host((size_t)count * 16);
     float *dev = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&dev, (size_t)count * 16 * sizeof(float)));
-    std::vector<float> host((size_t)count * 16);
     const DevCamera dc = make_camera(cam, w, h, contiguous_rows(0, h));
     rtk_debug_rays(d.scene, dc, row, x_step, count, dev, d.stream);
     hipError_t e = hipGetLastError();
@@ -1125,6 +1241,7 @@ int rt_debug_rays(rt_ctx *ctx, const rt_camera *cam, int w, int h, int row, int 
     for (int i = 0; i < count; i++) memcpy(&out[i], &host[(size_t)i * 16], sizeof(rt_debug_ray));
     *out_count = count;
     return RT_OK;
+    });
 }
 
 int rt_fxaa_device(rt_ctx *ctx, const int32_t *dev_pixels_in, int32_t *dev_pixels_out, int w, int h, void *hip_stream)
@@ -1136,16 +1253,19 @@ int rt_fxaa_device(rt_ctx *ctx, const int32_t *dev_pixels_in, int32_t *dev_pixel
     const size_t n = (size_t)w * (size_t)h;
     if (dev_pixels_in < dev_pixels_out + n && dev_pixels_out < dev_pixels_in + n)
         return fail(ctx, RT_ERR_INVALID_ARG, "the filter reads neighbours: input and output frames must not overlap");
+    return guarded(ctx, [&]() -> int {
     DeviceState &d = ctx->dev[0];
     HIP_TRY(ctx, hipSetDevice(d.device));
     rtk_fxaa(dev_pixels_in, dev_pixels_out, w, h, hip_stream ? static_cast<hipStream_t>(hip_stream) : d.stream);
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
+    });
 }
 
 int rt_unpin_pixels(rt_ctx *ctx)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
+    return guarded(ctx, [&]() -> int {
     if (ctx->pinned) {
         for (DeviceState &d : ctx->dev) {   // no copy into the range may be in flight
             HIP_TRY(ctx, hipSetDevice(d.device));
@@ -1158,6 +1278,7 @@ int rt_unpin_pixels(rt_ctx *ctx)
         HIP_TRY(ctx, hipHostUnregister(p));
     }
     return RT_OK;
+    });
 }
 
 int rt_pin_pixels(rt_ctx *ctx, int32_t *pixels, int64_t count)
@@ -1166,6 +1287,7 @@ int rt_pin_pixels(rt_ctx *ctx, int32_t *pixels, int64_t count)
     if (!pixels || count <= 0) return fail(ctx, RT_ERR_INVALID_ARG, "bad framebuffer range (%p, %lld)", (void *)pixels, (long long)count);
     int rc = rt_unpin_pixels(ctx);
     if (rc != RT_OK) return rc;
+    return guarded(ctx, [&]() -> int {
     HIP_TRY(ctx, hipSetDevice(ctx->dev[0].device));
     // Whole pages: every page that holds a byte of the array (all of them are mapped).
     const uintptr_t page = 4096, lo = (uintptr_t)pixels & ~(page - 1),
@@ -1181,6 +1303,7 @@ int rt_pin_pixels(rt_ctx *ctx, int32_t *pixels, int64_t count)
     ctx->pinned = pixels;
     ctx->pinned_count = (size_t)count;
     return RT_OK;
+    });
 }
 
 int rt_get_stats(rt_ctx *ctx, rt_stats *out)
@@ -1188,6 +1311,7 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out)
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (!out) return fail(ctx, RT_ERR_INVALID_ARG, "out is NULL");
     memset(out, 0, sizeof *out);
+    return guarded(ctx, [&]() -> int {
     out->num_devices = (int32_t)ctx->dev.size();
     double kernel_ms = 0.0, primary_ms = 0.0, trace_ms = 0.0, shade_ms = 0.0;
     for (DeviceState &d : ctx->dev) {
@@ -1251,6 +1375,7 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out)
     out->gather_ms = ctx->gather_ms;
     out->copy_ms = ctx->copy_ms;
     return RT_OK;
+    });
 }
 
 }  // extern "C"

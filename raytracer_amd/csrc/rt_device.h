@@ -163,6 +163,12 @@ struct DevFrame {
     int chain_policy;      // 1: k_trace_levels keeps the tiles the next level waits for to the workgroups that
                            // arrived first on their compute units, and the first of each free for them
     int num_cus;
+    // Host-visible outcome (page-locked host memory the device writes through the bus, and only
+    // when something went wrong): status[0] != 0 = a workgroup of k_trace_levels gave up waiting
+    // for a level to open, status[1] = that level.  Never cleared by the device.
+    int *status;
+    unsigned stall_ticks;  // how long a workgroup waits without progress, in ticks of the 100 MHz wall clock
+    int debug_withhold;    // test knob: the first reflecting tile of this level is never counted as done (-1: off)
 };
 
 // Launch wrappers (rt_kernels.hip).  All enqueue on `stream` and return at once.
@@ -173,7 +179,8 @@ void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting,
                hipStream_t stream);
 // Every level in one launch; grid_blocks = workgroups resident at once on the device
 // (rtk_trace_levels_resident_blocks), fewer if the frame has fewer tiles.
-int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus);
+// (of the instance rtk_trace_levels launches for a frame with that chain policy / counting mode)
+int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus, bool reserve, bool count);
 void rtk_trace_levels(const DevScene &s, const DevFrame &f, int grid_blocks, hipStream_t stream);
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
                      int grid_blocks, hipStream_t stream);

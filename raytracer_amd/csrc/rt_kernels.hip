@@ -1403,13 +1403,14 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
 //     slots, so no cache line of a per-slot array holds slots of two levels.
 // The chain ends at the first open level without A records (level max_depth never has any);
 // a workgroup leaves when the chain has ended and no B tile is left to claim.  A workgroup
-// that waits longer than SCHED_SPIN_LIMIT polls for a level to open sets sched->error and
-// leaves (the host reports it) so that no launch can spin forever.
+// that has waited DevFrame::stall_ticks (wall clock, about a second) for a level to open without
+// seeing any progress sets sched->error, reports the level it waited for in the host-visible
+// status block (DevFrame::status) and leaves, so that no launch can spin forever and the host
+// learns that the frame is incomplete whichever entry point enqueued it.
 // ---------------------------------------------------------------------------------------
 #define SCHED_JOB_EXIT 0
 #define SCHED_JOB_A 1
 #define SCHED_JOB_B 2
-#define SCHED_SPIN_LIMIT (1u << 23)   // x ~3.5 us per poll: ~30 s
 
 __device__ __forceinline__ int sched_load(const int *p)
 {
@@ -1422,7 +1423,6 @@ struct Taker {
     int seen_open;        // levels <= seen_open: record counts read
     int b_level;          // lowest level whose B queue may still hold an unclaimed tile
     bool a_left;          // level seen_open may still hold an unclaimed A tile
-    unsigned spins;
 };
 
 // RESERVE: the chain tiles are kept to the oldest workgroups of the compute units (see the claim
@@ -1450,7 +1450,7 @@ k_trace_levels(DevScene s, DevFrame f)
 #ifdef RT_PHASE_CLOCKS
     pc.t_last = __builtin_readcyclecounter();
 #endif
-    Taker tk = {0, -1, 0, false, 0u};
+    Taker tk = {0, -1, 0, false};
     if constexpr (RESERVE) {
         if (threadIdx.x == 0) {
             unsigned hw, xcc;
@@ -1465,6 +1465,7 @@ k_trace_levels(DevScene s, DevFrame f)
     for (;;) {
         if (threadIdx.x == 0) {
             int kind = SCHED_JOB_EXIT, lvl = 0, tile = 0, n = 0, walk = 0;
+            unsigned long long wait_since = 0ull;   // wall clock at the first idle poll of this wait
             for (;;) {
                 // What this workgroup believes is claimable, A tiles of the newest level first.
                 int *ctr = nullptr;
@@ -1523,12 +1524,20 @@ k_trace_levels(DevScene s, DevFrame f)
                     }
                     break;
                 }
-                if (ctr || opened) continue;
+                if (ctr || opened) {
+                    wait_since = 0ull;   // progress: a queue ran dry or a level opened
+                    continue;
+                }
                 // Nothing to claim in the levels seen so far.
                 if (tk.seen_open >= 0 && lv_a[tk.seen_open] == 0) break;   // the chain has ended: leave
                 // A tiles of the newest level are in flight (or the frame has not started): wait.
-                if (++tk.spins >= SCHED_SPIN_LIMIT) {
+                const unsigned long long now = wall_clock64();
+                if (wait_since == 0ull) wait_since = now;
+                else if (now - wait_since > (unsigned long long)f.stall_ticks) {
                     atomicExch(&sc->error, 1);
+                    // Host-visible (page-locked host memory): the level, then the flag.
+                    __hip_atomic_store(&f.status[1], tk.seen_open + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(&f.status[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(127);
@@ -1555,7 +1564,8 @@ k_trace_levels(DevScene s, DevFrame f)
             __syncthreads();
             if (threadIdx.x == 0) {
                 const int tiles_a = (n + 255) >> 8;
-                if (atomicAdd(&sc->done_a[lvl], 1) + 1 == tiles_a) {
+                // (debug_withhold: a test knob that loses one tile's count, so that the next level never opens)
+                if (!(lvl == f.debug_withhold && tile == 0) && atomicAdd(&sc->done_a[lvl], 1) + 1 == tiles_a) {
 #ifdef RT_SCHED_TIMELINE
                     sc->t_open[lvl + 1] = (unsigned long long)wall_clock64();
 #endif
@@ -1899,10 +1909,10 @@ static trace_levels_kernel trace_levels_for(const DevScene &s, bool reserve = fa
     return count ? trace_levels_pick<false, true>(s) : trace_levels_pick<false, false>(s);
 }
 
-int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus)
+int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus, bool reserve, bool count)
 {
     int per_cu = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_levels_for(s), 256, 0);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_levels_for(s, reserve, count), 256, 0);
     if (e != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 1;

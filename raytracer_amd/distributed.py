@@ -116,13 +116,31 @@ class FrameGatherer:
         return self.frame
 
     def _gather(self) -> None:
-        dist.gather(self._send, self._recv if self.rank == 0 else None, dst=0, group=self.group)
+        if self._send.is_cuda and dist.get_backend(self.group) == "gloo":
+            self._gather_through_host()
+        else:
+            dist.gather(self._send, self._recv if self.rank == 0 else None, dst=0, group=self.group)
         if self.rank == 0:
             if self.interleave:
                 torch.index_select(self._stacked.view(-1, self.width), 0, self._perm, out=self.frame)
             elif not self.equal:
                 for (a, b), buf in zip(self._blocks, self._recv):
                     self.frame[a:b].copy_(buf[: b - a])
+
+
+    def _gather_through_host(self) -> None:
+        """gloo with device tensors (ranks rehearsed on fewer GPUs than ranks): the blocks travel
+        through host memory on THIS gatherer's stream.  Handing gloo the device tensors would make
+        it copy them on high-priority side streams of its own, and on a GPU that two processes
+        share a high-priority stream waiting for a kernel of a normal-priority one pauses both
+        processes' queues for seconds at a time (measured with a plain busy-wait kernel as well:
+        tools/two_rank_probe.py); host tensors keep gloo off the device."""
+        host_send = self._send.cpu()   # on the current stream, behind the frame's kernels; blocking
+        host_recv = [torch.empty_like(host_send) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(host_send, host_recv, dst=0, group=self.group)
+        if self.rank == 0:
+            for dst, src in zip(self._recv, host_recv):
+                dst.copy_(src, non_blocking=False)
 
 
 class FramePipeline:

@@ -118,6 +118,11 @@ class RenderContext:
             self._ctx, C.byref(camera.as_struct()), width, height, band_rows, part, parts, max_depth,
             C.c_void_p(dev_ptr), C.c_void_p(stream)))
 
+    def frame_status(self) -> None:
+        """rt_frame_status: waits for the frames enqueued with render_*_device so far and raises
+        RtError (RT_ERR_STALLED) if the device gave up on one of them."""
+        self._check(self._lib.rt_frame_status(self._ctx))
+
     def debug_rays(self, camera: Camera, width: int, height: int, row: int = 320, x_step: int = 10) -> np.ndarray:
         """rt_debug_rays as a structured array (direction, prim, hit, t, normal, reflected): the
         rays Raytracer.Debug draws (MyApplication.cs:459-478: row 320, every 10th pixel)."""

@@ -22,7 +22,8 @@ def test_library_exports_every_declared_symbol():
     lib = abi.load_library()
     for name in declared_functions():
         assert getattr(lib, name) is not None, name
-    assert lib.rt_api_version() == 3
+    header = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
+    assert lib.rt_api_version() == int(re.search(r"#define RT_API_VERSION (\d+)", header).group(1)) == 4
 
 
 def test_struct_sizes_match_the_header_layout():
