@@ -253,7 +253,29 @@ int rt_render_rows_device(rt_ctx *ctx, const rt_camera *camera, int width, int h
                           int32_t *dev_pixels_out, void *hip_stream);
 
 /*
- * The same for an interleaved partition of the frame: the frame is cut into bands of band_rows
+ * rt_render_rows_device for callers that cannot allocate (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc): same arguments, same pixels, but the frame's
+ * ray queues live in a fixed array of RT_NOALLOC_SCRATCH_BYTES that the library holds in every
+ * GPU's memory from load to process exit, and the call makes no allocation of any kind.  The
+ * frame must fit: with P = (row_end - row_begin) * width rounded up to a multiple of 64,
+ *     P * (max_depth + 1) * (48 + 4 * ceil(lights / 32)) + 280 KiB  <=  RT_NOALLOC_SCRATCH_BYTES
+ * (e.g. 360 x 360 pixels at max_depth 4, or 1024 x 100 at max_depth 5, with up to 32 lights),
+ * else RT_ERR_LIMIT and nothing is enqueued; render a taller frame as several calls of fewer
+ * rows.  ALL contexts of a process share a GPU's array: calls that overlap on one GPU (two
+ * contexts, or two streams not ordered against each other) race on it; calls ordered one after
+ * the other are independent, each clears what it needs.  The context must have been used once
+ * before the no-allocation phase begins (rt_set_scene, and one render call of either kind so
+ * that the runtime has loaded the kernels).
+ * No counterpart in the reference (its loop allocates freely, objects.cs:125); exists for
+ * callers that cannot allocate.
+ */
+#define RT_NOALLOC_SCRATCH_BYTES (32u << 20)
+int rt_render_rows_device_noalloc(rt_ctx *ctx, const rt_camera *camera, int width, int height,
+                                  int row_begin, int row_end, int max_depth,
+                                  int32_t *dev_pixels_out, void *hip_stream);
+
+/*
+ * rt_render_rows_device for an interleaved partition of the frame: the frame is cut into bands of band_rows
  * consecutive rows (band b = rows [b * band_rows, (b + 1) * band_rows), the last one shorter)
  * and this call renders the bands b = part, part + parts, part + 2 * parts, ...  The bands are
  * written one after the other: dev_pixels_out points to rt_band_rows(height, band_rows, part,

@@ -14,6 +14,7 @@ RT_PRIM_TRIANGLE = 2
 RT_REFERENCE_MAX_DEPTH = 5
 RT_MAX_DEPTH = 16
 RT_MAX_TEXTURES = 8
+RT_NOALLOC_SCRATCH_BYTES = 32 << 20
 
 RT_OK = 0
 STATUS_NAMES = {
@@ -114,6 +115,11 @@ EXPORTS = {
         [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_void_p],
     ),
     "rt_render_rows_device": (
+        C.c_int,
+        [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+         C.c_void_p, C.c_void_p],
+    ),
+    "rt_render_rows_device_noalloc": (
         C.c_int,
         [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
          C.c_void_p, C.c_void_p],

@@ -17,11 +17,25 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
 
+// Scratch of rt_render_rows_device_noalloc, the entry point that allocates nothing: the ray
+// queues, occlusion words and control block of ONE frame of bounded size.  Every GPU the library
+// runs on holds its own copy of this array from the moment the library is loaded until the
+// process ends.  In host code the array's name is only a handle for hipGetSymbolAddress: the
+// address the kernels get is the one that call returned for the device in question
+// (scratch_address below), never the name itself.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
 namespace {
+
+// Device address of `scratch` on each device, asked for once per device with that device current.
+constexpr int RT_SCRATCH_TABLE = 64;
+std::mutex g_scratch_lock;
+unsigned char *g_scratch_address[RT_SCRATCH_TABLE] = {};
 
 // Below this many level-0 tiles per resident workgroup a frame is bound by its chain of levels.
 constexpr int RT_CHAIN_BOUND_TILES_PER_WORKGROUP = 8;
@@ -79,7 +93,11 @@ struct DeviceState {
     void *tex_mem[RT_MAX_TEXTURES] = {};
 
     // per-frame scratch
-    DevFrame frame{};
+    DevFrame frame{};          // in memory this context allocated (grown on demand)
+    DevFrame fixed{};          // in the library's fixed scratch array (rt_render_rows_device_noalloc)
+    bool last_fixed = false;   // which of the two the last render call used
+    DevFrame &last() { return last_fixed ? fixed : frame; }
+    unsigned char *scratch_base = nullptr;   // this device's copy of the fixed scratch array
     size_t cap_slots = 0, cap_mask = 0;
     int32_t *out = nullptr;  // device framebuffer block of this device
     size_t cap_out = 0;
@@ -558,6 +576,65 @@ DevCamera make_camera(const rt_camera *cam, int w, int h, const RowSet &rs)
     return c;
 }
 
+// This device's copy of the fixed scratch array.  `device` must be the current device: the
+// address hipGetSymbolAddress returns is the current device's.
+hipError_t scratch_address(int device, unsigned char **out)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_lock);
+    if (device >= 0 && device < RT_SCRATCH_TABLE && g_scratch_address[device]) {
+        *out = g_scratch_address[device];
+        return hipSuccess;
+    }
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    *out = static_cast<unsigned char *>(p);
+    if (device >= 0 && device < RT_SCRATCH_TABLE) g_scratch_address[device] = *out;
+    return hipSuccess;
+}
+
+// Bytes of the fixed scratch array a frame of P pixels, max_depth + 1 levels and nl lights needs:
+// the control block, then the three record arrays and the occlusion words, each starting on a
+// multiple of 256 bytes.
+size_t fixed_frame_bytes(size_t slots, int words)
+{
+    const size_t rec = (slots * sizeof(float4) + 255) / 256 * 256;
+    const size_t mask = (slots * (size_t)words * sizeof(uint32_t) + 255) / 256 * 256;
+    return FRAME_CONTROL_BYTES + 3 * rec + mask;
+}
+
+// d.fixed := a frame of P pixels laid out in this device's copy of the fixed scratch array.
+// Allocates nothing; a frame that does not fit is refused.
+int place_fixed_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
+{
+    const int levels = max_depth + 1;
+    const size_t stride = ((size_t)P + RT_LEVEL_ALIGN - 1) / RT_LEVEL_ALIGN * RT_LEVEL_ALIGN;
+    const size_t slots = stride * (size_t)levels;
+    const int words = std::max(1, (nl + 31) / 32);
+    const size_t need = fixed_frame_bytes(slots, words);
+    if (need > (size_t)RT_NOALLOC_SCRATCH_BYTES)
+        return fail(ctx, RT_ERR_LIMIT, "%d pixels x %d levels x %d lights need %zu bytes of ray queues; the fixed scratch "
+                    "of rt_render_rows_device_noalloc holds %zu (use rt_render_rows_device, or fewer rows per call)",
+                    P, levels, nl, need, (size_t)RT_NOALLOC_SCRATCH_BYTES);
+    if (!d.scratch_base) return fail(ctx, RT_ERR_HIP, "device %d: the fixed scratch array has no address", d.device);
+    unsigned char *p = d.scratch_base;
+    const size_t rec = (slots * sizeof(float4) + 255) / 256 * 256;
+    DevFrame &f = d.fixed;
+    f.counters = reinterpret_cast<DevCounters *>(p);
+    f.sched = reinterpret_cast<DevSched *>(p + RT_COUNTER_SLOTS * sizeof(DevCounters));
+    f.cnt = reinterpret_cast<int *>(p + RT_COUNTER_SLOTS * sizeof(DevCounters) + sizeof(DevSched));
+    p += FRAME_CONTROL_BYTES;
+    f.recA = reinterpret_cast<float4 *>(p);
+    f.recB = reinterpret_cast<float4 *>(p + rec);
+    f.refl = reinterpret_cast<float4 *>(p + 2 * rec);
+    f.mask = reinterpret_cast<uint32_t *>(p + 3 * rec);
+    f.P = (int)stride;
+    f.slots = (int)slots;
+    f.max_depth = max_depth;
+    f.mask_words = words;
+    return RT_OK;
+}
+
 int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
 {
     const int levels = max_depth + 1;
@@ -627,11 +704,11 @@ int check_schedule(rt_ctx *ctx, DeviceState &d)
 {
     static_assert(RT_DEV_MAX_LEVELS >= RT_MAX_DEPTH + 2, "DevSched holds one entry per level");
     static const bool trace = getenv("RT_HIP_SCHED_TRACE") != nullptr;
-    if (trace && d.frame.sched && d.snap_parts == 0) {
+    if (trace && d.last().sched && d.snap_parts == 0) {
         DevSched sc;
         std::vector<int> cnt(2 * (size_t)(d.last_depth + 2));
-        HIP_TRY(ctx, hipMemcpy(&sc, d.frame.sched, sizeof sc, hipMemcpyDeviceToHost));
-        (void)hipMemcpy(cnt.data(), d.frame.cnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost);
+        HIP_TRY(ctx, hipMemcpy(&sc, d.last().sched, sizeof sc, hipMemcpyDeviceToHost));
+        (void)hipMemcpy(cnt.data(), d.last().cnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost);
         fprintf(stderr, "[rt_hip] trace launch: %.1f us;", (double)(sc.t_last - sc.t_first) * 0.01);
         for (int k = 1; k <= sc.open_level && k < RT_DEV_MAX_LEVELS; k++)
             fprintf(stderr, " L%d opens at %.1f (A %d B %d)", k, (double)(sc.t_open[k] - sc.t_first) * 0.01,
@@ -647,11 +724,11 @@ int check_schedule(rt_ctx *ctx, DeviceState &d)
         // What the schedule of the LAST frame looked like when it ended (the stalled frame's own, if
         // the caller checks after every frame).
         int claimed = -1, done = -1, records = -1;
-        if (d.frame.sched && level >= 1 && level < RT_DEV_MAX_LEVELS) {
+        if (d.last().sched && level >= 1 && level < RT_DEV_MAX_LEVELS) {
             DevSched sc;
             int cnt[2 * RT_DEV_MAX_LEVELS];
-            if (hipMemcpy(&sc, d.frame.sched, sizeof sc, hipMemcpyDeviceToHost) == hipSuccess &&
-                hipMemcpy(cnt, d.frame.cnt, sizeof cnt, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (hipMemcpy(&sc, d.last().sched, sizeof sc, hipMemcpyDeviceToHost) == hipSuccess &&
+                hipMemcpy(cnt, d.last().cnt, sizeof cnt, hipMemcpyDeviceToHost) == hipSuccess) {
                 claimed = sc.next_a[level - 1];
                 done = sc.done_a[level - 1];
                 records = cnt[2 * (level - 1)];
@@ -670,8 +747,9 @@ int check_schedule(rt_ctx *ctx, DeviceState &d)
 // part < 0: the call is a frame of its own.  part >= 0: part `part` of a frame rendered in parts —
 // the work counters run on from the earlier parts and the part's outcome is copied to
 // d.outcome_snap behind its kernels.
+// fixed_scratch: the frame's queues live in the library's fixed scratch array and nothing is allocated.
 int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h, const RowSet &rs,
-                 int max_depth, int32_t *dev_pixels, hipStream_t stream, int part = -1)
+                 int max_depth, int32_t *dev_pixels, hipStream_t stream, int part = -1, bool fixed_scratch = false)
 {
     const long long P64 = (long long)rs.rows * (long long)w;
     if (P64 > INT32_MAX) return fail(ctx, RT_ERR_LIMIT, "row block of %lld pixels exceeds 2^31-1", P64);
@@ -683,8 +761,10 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     HIP_TRY(ctx, hipSetDevice(d.device));
     if (part >= 0 && !d.outcome_snap)
         HIP_TRY(ctx, hipHostMalloc((void **)&d.outcome_snap, RT_MAX_FRAME_PARTS * FRAME_OUTCOME_BYTES, hipHostMallocDefault));
-    int rc = ensure_frame(ctx, d, P, max_depth, d.scene.nl);
+    int rc = fixed_scratch ? place_fixed_frame(ctx, d, P, max_depth, d.scene.nl) : ensure_frame(ctx, d, P, max_depth, d.scene.nl);
     if (rc != RT_OK) return rc;
+    d.last_fixed = fixed_scratch;
+    DevFrame &fr = d.last();
     const DevCamera dc = make_camera(cam, w, h, rs);
     const int tiles0 = (P + 255) / 256;
     const bool counting = ctx->profiling == 1;   // the counting kernels walk everything
@@ -702,31 +782,31 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // frame the chain IS the frame time and the ray walks alone (shortest chain).
     static const char *first_env = getenv("RT_HIP_FIRST_LIGHTS");
     const int shared_walk = d.scene.nl >= 4 ? 3 : 2;
-    d.frame.first_lights = tiles0 >= RT_CHAIN_BOUND_TILES_PER_WORKGROUP * resident_plain ? shared_walk : 0;
-    if (first_env) d.frame.first_lights = std::max(0, std::min(atoi(first_env), shared_walk));
-    d.frame.any_hit = counting ? 0 : 1;
+    fr.first_lights = tiles0 >= RT_CHAIN_BOUND_TILES_PER_WORKGROUP * resident_plain ? shared_walk : 0;
+    if (first_env) fr.first_lights = std::max(0, std::min(atoi(first_env), shared_walk));
+    fr.any_hit = counting ? 0 : 1;
     // On still smaller frames (measured: below ~6 tiles per resident workgroup; 4K / 8 GPUs has 4)
     // it pays to reserve the oldest workgroup of every compute unit for the chain: a SIMD issues
     // for its oldest waves first, so a chain tile in a young workgroup crawls while its elders
     // have work.  1/8 of the 4K frame: 0.397 -> 0.362 ms; 1/4 (8 tiles per workgroup): 0.547 ->
     // 0.571, hence the bound.  RT_HIP_CHAIN_POLICY=0/1 (tuning aid) overrides.
     static const char *policy_env = getenv("RT_HIP_CHAIN_POLICY");
-    d.frame.chain_policy = policy_env ? (atoi(policy_env) != 0)
+    fr.chain_policy = policy_env ? (atoi(policy_env) != 0)
                                       : tiles0 < RT_CHAIN_RESERVED_TILES_PER_WORKGROUP * resident_plain;
-    d.frame.num_cus = d.num_cus;
+    fr.num_cus = d.num_cus;
     // ... and for the instance this frame launches (workgroups beyond what is resident at once
     // would only start when the first ones leave, find nothing to claim and exit).
-    const int resident_blocks = resident(d.frame.chain_policy != 0);
-    d.frame.status = d.status;
+    const int resident_blocks = resident(fr.chain_policy != 0);
+    fr.status = d.status;
     const char *stall_env = getenv("RT_HIP_STALL_MS");   // (read at every call, like the knob below)
     const long long stall_ms = stall_env && atoll(stall_env) > 0 ? atoll(stall_env) : (long long)RT_STALL_MS_DEFAULT;
-    d.frame.stall_ticks = (unsigned)std::min<long long>(stall_ms * 100000ll, 4000000000ll);   // 100 MHz wall clock
+    fr.stall_ticks = (unsigned)std::min<long long>(stall_ms * 100000ll, 4000000000ll);   // 100 MHz wall clock
     // RT_HIP_DEBUG_WITHHOLD_LEVEL (test knob, read at every call): the level whose first reflecting
     // tile is never counted as done, which stalls the schedule there on purpose.
     const char *withhold_env = getenv("RT_HIP_DEBUG_WITHHOLD_LEVEL");
-    d.frame.debug_withhold = withhold_env ? atoi(withhold_env) : -1;
+    fr.debug_withhold = withhold_env ? atoi(withhold_env) : -1;
     d.last_stream = stream;
-    const DevFrame &f = d.frame;
+    const DevFrame &f = fr;
     if (part > 0) HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, FRAME_CONTROL_BYTES - RT_COUNTER_SLOTS * sizeof(DevCounters), stream));
     else HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, FRAME_CONTROL_BYTES, stream));
     d.timed = ctx->profiling != 0;
@@ -810,6 +890,7 @@ int rt_create(rt_ctx **out, const int *device_ids, int n_devices)
         for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipEventCreate(&d.ev[k]);
         if (e == hipSuccess) e = hipHostMalloc((void **)&d.status, 64, hipHostMallocMapped);
         if (e == hipSuccess) memset(d.status, 0, 64);
+        if (e == hipSuccess) e = scratch_address(d.device, &d.scratch_base);
         if (e != hipSuccess) {
             int rc = fail(nullptr, RT_ERR_HIP, "device %d setup failed: %s", d.device, hipGetErrorString(e));
             rt_destroy(ctx);
@@ -957,6 +1038,26 @@ int rt_render_rows_device(rt_ctx *ctx, const rt_camera *cam, int w, int h, int r
     for (size_t i = 1; i < ctx->dev.size(); i++) ctx->dev[i].last_P = 0;
     return enqueue_rows(ctx, d, cam, w, h, contiguous_rows(row_begin, row_end), max_depth, dev_pixels_out,
                         hip_stream ? static_cast<hipStream_t>(hip_stream) : d.stream);
+    });
+}
+
+int rt_render_rows_device_noalloc(rt_ctx *ctx, const rt_camera *cam, int w, int h, int row_begin, int row_end,
+                                  int max_depth, int32_t *dev_pixels_out, void *hip_stream)
+{
+    int rc = check_render_args(ctx, cam, w, h, max_depth);
+    if (rc != RT_OK) return rc;
+    if (row_begin < 0 || row_end > h || row_begin > row_end)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rows [%d, %d) outside [0, %d)", row_begin, row_end, h);
+    if (!dev_pixels_out && row_end > row_begin) return fail(ctx, RT_ERR_INVALID_ARG, "dev_pixels_out is NULL");
+    return guarded(ctx, [&]() -> int {
+    DeviceState &d = ctx->dev[0];
+    ctx->last_was_rows_device = true;
+    ctx->last_w = w;
+    ctx->last_h = h;
+    ctx->copy_ms = ctx->gather_ms = 0.0;
+    for (size_t i = 1; i < ctx->dev.size(); i++) ctx->dev[i].last_P = 0;
+    return enqueue_rows(ctx, d, cam, w, h, contiguous_rows(row_begin, row_end), max_depth, dev_pixels_out,
+                        hip_stream ? static_cast<hipStream_t>(hip_stream) : d.stream, -1, true);
     });
 }
 
@@ -1315,7 +1416,7 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out)
     out->num_devices = (int32_t)ctx->dev.size();
     double kernel_ms = 0.0, primary_ms = 0.0, trace_ms = 0.0, shade_ms = 0.0;
     for (DeviceState &d : ctx->dev) {
-        if (d.last_P == 0 || !d.frame.cnt) continue;
+        if (d.last_P == 0 || !d.last().cnt) continue;
         HIP_TRY(ctx, hipSetDevice(d.device));
         HIP_TRY(ctx, hipDeviceSynchronize());
         std::vector<int> cnt(2 * (size_t)(d.last_depth + 2));
@@ -1327,13 +1428,13 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out)
                 for (size_t i = 0; i < cnt.size(); i++) cnt[i] += part_cnt[i];
             }
         } else {
-            HIP_TRY(ctx, hipMemcpy(cnt.data(), d.frame.cnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(cnt.data(), d.last().cnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
         }
         {
             static_assert(sizeof(DevCounters) % sizeof(uint64_t) == 0, "DevCounters is an array of 64-bit counts");
             constexpr size_t words = sizeof(DevCounters) / sizeof(uint64_t);
             std::vector<uint64_t> slots(RT_COUNTER_SLOTS * words);
-            HIP_TRY(ctx, hipMemcpy(slots.data(), d.frame.counters, slots.size() * sizeof(uint64_t),
+            HIP_TRY(ctx, hipMemcpy(slots.data(), d.last().counters, slots.size() * sizeof(uint64_t),
                                    hipMemcpyDeviceToHost));
             uint64_t sum[words] = {};
             for (size_t i = 0; i < slots.size(); i++) sum[i % words] += slots[i];

@@ -110,6 +110,14 @@ class RenderContext:
             self._ctx, C.byref(camera.as_struct()), width, height, row_begin, row_end, max_depth,
             C.c_void_p(dev_ptr), C.c_void_p(stream)))
 
+    def render_rows_device_noalloc(self, camera: Camera, width: int, height: int, row_begin: int,
+                                   row_end: int, max_depth: int, dev_ptr: int, stream: int = 0) -> None:
+        """rt_render_rows_device_noalloc: render_rows_device with the ray queues in the library's
+        fixed scratch array; raises RtError (RT_ERR_LIMIT) when the rows do not fit it."""
+        self._check(self._lib.rt_render_rows_device_noalloc(
+            self._ctx, C.byref(camera.as_struct()), width, height, row_begin, row_end, max_depth,
+            C.c_void_p(dev_ptr), C.c_void_p(stream)))
+
     def render_bands_device(self, camera: Camera, width: int, height: int, band_rows: int,
                             part: int, parts: int, max_depth: int, dev_ptr: int, stream: int = 0) -> None:
         """rt_render_bands_device: every parts-th band of band_rows rows, starting with band
