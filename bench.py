@@ -135,14 +135,20 @@ def main() -> None:
 
     cam = Camera()
     flat = cfg["scene"]().flatten()
-    ctx = RenderContext([dev_index])
-    ctx.set_scene(flat)
-    # Several ranks: two frames in flight, so that a frame's gather (and rank 0's row
-    # permutation) runs while the next frame renders.
-    pipeline = FramePipeline(W, H, rank, world, device, depth=2 if world > 1 else 1)
+    # One GPU: one frame at a time (what the C# host's blocking Render() sees, and the condition
+    # the kernel durations below are measured under).  Several ranks: frames in flight, each in a
+    # render context of its own, so that a frame's gather (and rank 0's row permutation) and the
+    # idle stretches of its chain of reflection levels are filled by the next frames' kernels.
+    in_flight = int(os.environ.get("RT_BENCH_FRAMES_IN_FLIGHT", "0")) or (1 if world == 1 else 3 if world >= 8 else 2)
+    contexts = [RenderContext([dev_index]) for _ in range(in_flight)]
+    for c in contexts:
+        c.set_scene(flat)
+        c.set_device_share(in_flight)
+    ctx = contexts[0]
+    pipeline = FramePipeline(W, H, rank, world, device, depth=in_flight, contexts=contexts)
 
     def step() -> None:
-        pipeline.render_frame(ctx, cam, DEPTH)
+        pipeline.render_frame(None, cam, DEPTH)
 
     def fence() -> None:
         torch.cuda.synchronize()
@@ -162,11 +168,14 @@ def main() -> None:
     # Did the device finish every frame it was given?  (A stalled level schedule leaves a frame
     # incomplete; its time must not be reported.)  Every rank checks, every rank learns the result.
     stalled = 0.0
-    try:
-        ctx.frame_status()
-    except RtError as e:
-        print(f"[bench rank {rank}] {e}", file=sys.stderr, flush=True)
-        stalled = 1.0
+    for c in contexts:
+        try:
+            c.frame_status()
+        except RtError as e:
+            print(f"[bench rank {rank}] {e}", file=sys.stderr, flush=True)
+            stalled = 1.0
+    for c in contexts:   # what follows measures one frame at a time on the first context
+        c.set_device_share(1)
 
     # Kernel durations of the SAME kernels the timed loop ran: a few more frames bracketed by HIP
     # events on the stream (profiling mode 2), averaged.
@@ -174,14 +183,14 @@ def main() -> None:
     ev = {"trace_ms": 0.0, "kernel_ms": 0.0, "primary_ms": 0.0, "shade_ms": 0.0}
     EVENT_FRAMES = 5
     for _ in range(EVENT_FRAMES):
-        render_block(ctx, cam, W, H, DEPTH, pipeline.begin())
+        render_block(ctx, cam, W, H, DEPTH, pipeline.slots[0])
         timed = ctx.stats()  # synchronises
         for k in ev:
             ev[k] += timed[k] / EVENT_FRAMES
     # One more frame with the device-side work counters on (profiling mode 1: the counting
     # instances of the kernels, a few per cent slower; only their counts are used).
     ctx.set_profiling(1)
-    render_block(ctx, cam, W, H, DEPTH, pipeline.begin())
+    render_block(ctx, cam, W, H, DEPTH, pipeline.slots[0])
     st = ctx.stats()
     ctx.set_profiling(0)
 
@@ -189,12 +198,12 @@ def main() -> None:
     # timed on its own; N = 1 below (rank 0 only).
     handoff = {}
     if world > 1:
-        g = pipeline.begin()
+        g = pipeline.slots[0]
         render_block(ctx, cam, W, H, DEPTH, g)
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         with torch.cuda.stream(g.stream):
             e0.record()
-        pipeline.finish(g)
+        g.gather()
         host = torch.empty((H, W), dtype=torch.int32, pin_memory=True) if rank == 0 else None
         with torch.cuda.stream(g.stream):
             e1.record()
@@ -222,7 +231,8 @@ def main() -> None:
     tot = dict(zip(keys, totals.tolist()))
     elapsed, trace_ms, kernel_ms, primary_ms, shade_ms, stalled = times.tolist()
     if stalled:
-        ctx.close()
+        for c in contexts:
+            c.close()
         raise SystemExit("bench: the device gave up on a frame of the timed loop (see stderr); no result")
 
     if rank == 0:
@@ -264,7 +274,9 @@ def main() -> None:
                 "spheres": ns, "planes": npl, "lights": flat.num_lights,
                 "partition": ("whole frame on one GPU" if world == 1 else
                               f"every {world}th band of 16 rows per rank, {backend} gather to rank 0, "
-                              "two frames in flight (a frame's gather overlaps the next frame's rendering)"),
+                              f"{in_flight} frames in flight per rank, each in a render context of its own (a frame's "
+                              "gather and the idle stretches of its level chain overlap the next frames' kernels)"),
+                "frames_in_flight": in_flight,
                 "rays_counted": "primary + shadow + secondary (one shadow ray per shaded hit and light, one "
                                 "secondary ray per shaded specular hit below the depth bound, de-duplicated per level)",
                 "rays_per_frame": {"primary": int(tot["rays_primary"]), "shadow": int(tot["rays_shadow"]),
@@ -321,7 +333,8 @@ def main() -> None:
             line["cpu_baseline"] = cpu_baseline(cfg, flat, cam)
         print(json.dumps(line), flush=True)
 
-    ctx.close()
+    for c in contexts:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
         faulthandler.cancel_dump_traceback_later()

@@ -290,6 +290,17 @@ int rt_render_bands_device(rt_ctx *ctx, const rt_camera *camera, int width, int 
                            int band_rows, int part, int parts, int max_depth,
                            int32_t *dev_pixels_out, void *hip_stream);
 
+/*
+ * Tell the context that `contexts` contexts (1..8, this one included) render on its devices AT
+ * THE SAME TIME, each on a stream of its own: later render calls size their resident launches
+ * for 1/contexts of the device, so that the frames of the contexts run side by side instead of
+ * one after the other.  What it is for: small frames (a rank's share of a frame split over
+ * several GPUs) are bound by their chain of dependent reflection levels, during which most of
+ * the device idles; two or three such frames in flight, each in a context of its own, fill it.
+ * Default 1.  No counterpart in the reference (one frame at a time, MyApplication.cs:179-193).
+ */
+int rt_set_device_share(rt_ctx *ctx, int contexts);
+
 /* Rows of a height-row frame that fall to `part` of `parts` with bands of band_rows rows, or
  * RT_ERR_INVALID_ARG. */
 int rt_band_rows(int height, int band_rows, int part, int parts);

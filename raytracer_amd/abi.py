@@ -131,6 +131,7 @@ EXPORTS = {
     ),
     "rt_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "rt_frame_status": (C.c_int, [C.c_void_p]),
+    "rt_set_device_share": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_debug_rays": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.POINTER(rt_debug_ray), C.POINTER(C.c_int)]),
     "rt_fxaa_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

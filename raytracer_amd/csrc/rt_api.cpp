@@ -125,6 +125,7 @@ struct rt_ctx {
     char error[RT_ERROR_CHARS] = "";
     bool have_scene = false;
     int profiling = 0;             // RT_PROFILE_*: 0 off, 1 counters and event timing, 2 event timing only
+    int share = 1;                 // contexts rendering on this context's devices at the same time (rt_set_device_share)
     int num_prims = 0, num_lights = 0, ns = 0, np = 0, nt = 0;
     uint32_t textures_used = 0;    // bit i: some primitive names texture slot i
     uint32_t textures_loaded = 0;  // bit i: slot i holds an image
@@ -775,7 +776,11 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
         if (r <= 0) r = rtk_trace_levels_resident_blocks(d.scene, d.num_cus, reserve, counting);
         return r;
     };
-    const int resident_plain = resident(false);
+    // A context that shares its device with others rendering at the same time takes its part of
+    // the device: the level kernel's workgroups stay resident for the whole launch, so two
+    // full-size launches would run one after the other instead of side by side.
+    const int share = std::max(1, ctx->share);
+    const int resident_plain = std::max(d.num_cus / 2, resident(false) / share);
     // The walk that carries a record's reflection ray is the one the next level waits for.
     // With plenty of tiles per resident workgroup the chain of levels hides behind the other
     // work and the ray shares its walk with the first lights (fewest instructions); on a small
@@ -796,7 +801,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     fr.num_cus = d.num_cus;
     // ... and for the instance this frame launches (workgroups beyond what is resident at once
     // would only start when the first ones leave, find nothing to claim and exit).
-    const int resident_blocks = resident(fr.chain_policy != 0);
+    const int resident_blocks = std::max(d.num_cus / 2, resident(fr.chain_policy != 0) / share);
     fr.status = d.status;
     const char *stall_env = getenv("RT_HIP_STALL_MS");   // (read at every call, like the knob below)
     const long long stall_ms = stall_env && atoll(stall_env) > 0 ? atoll(stall_env) : (long long)RT_STALL_MS_DEFAULT;
@@ -816,8 +821,8 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // resident at once (4 per compute unit) when each gets several tiles, twice that on small frames
     // (measured: 3840x2160 0.161 against 0.170 ms, 1920x1080 0.050 against 0.048 ms).
     const int tiles32 = ((w + 31) / 32) * ((rs.rows + 31) / 32);
-    rtk_primary(d.scene, dc, f, dev_pixels, std::min(tiles32 >= 16 * d.num_cus ? d.num_cus * 4 : d.num_cus * 8, RT_COUNTER_SLOTS),
-                stream);
+    rtk_primary(d.scene, dc, f, dev_pixels,
+                std::min((tiles32 >= 16 * d.num_cus ? d.num_cus * 4 : d.num_cus * 8) / share, RT_COUNTER_SLOTS), stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[1], stream));
     // RT_HIP_LEVEL_KERNELS=1 (profiling aid): one launch per queue per level on this stream,
     // so that a kernel trace shows what each level costs on its own.
@@ -960,6 +965,14 @@ int rt_set_profiling(rt_ctx *ctx, int enable)
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (enable < 0 || enable > 2) return fail(ctx, RT_ERR_INVALID_ARG, "profiling mode %d is none of 0, 1, 2", enable);
     ctx->profiling = enable;
+    return RT_OK;
+}
+
+int rt_set_device_share(rt_ctx *ctx, int contexts)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (contexts < 1 || contexts > 8) return fail(ctx, RT_ERR_INVALID_ARG, "device share %d outside [1, 8]", contexts);
+    ctx->share = contexts;
     return RT_OK;
 }
 

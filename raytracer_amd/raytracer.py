@@ -126,6 +126,10 @@ class RenderContext:
             self._ctx, C.byref(camera.as_struct()), width, height, band_rows, part, parts, max_depth,
             C.c_void_p(dev_ptr), C.c_void_p(stream)))
 
+    def set_device_share(self, contexts: int) -> None:
+        """rt_set_device_share: this many contexts render on the device at the same time."""
+        self._check(self._lib.rt_set_device_share(self._ctx, int(contexts)))
+
     def frame_status(self) -> None:
         """rt_frame_status: waits for the frames enqueued with render_*_device so far and raises
         RtError (RT_ERR_STALLED) if the device gave up on one of them."""

@@ -479,3 +479,31 @@ def test_two_device_states_split_rows_and_gather(oracle):
             gpu = three.render(cam, w, h, 5)
             ref, _ = oracle.render(fs, cam, w, h, max_depth=5)
             assert np.array_equal(gpu, ref), (w, h)
+
+
+def test_pipeline_with_a_context_per_slot_renders_frames_side_by_side(oracle):
+    """FramePipeline built with one render context per slot: the slots' frames render at the same
+    time on streams of their own (each context sized for a third of the device) and every frame
+    is the frame its camera asks for."""
+    import torch
+    from raytracer_amd.distributed import FramePipeline
+    fs = scene_1k().flatten()
+    w, h, depth = 480, 270, 3
+    ctxs = [RenderContext() for _ in range(3)]
+    for c in ctxs:
+        c.set_scene(fs)
+        c.set_device_share(3)
+    pipe = FramePipeline(w, h, 0, 1, torch.device("cuda", 0), depth=3, contexts=ctxs)
+    cams = [Camera(position=(0.04 * i, -0.02 * i, 0.0)) for i in range(9)]
+    frames = [pipe.render_frame(None, cam, depth) for cam in cams]
+    pipe.synchronize()
+    for c in ctxs:
+        c.frame_status()
+    assert len({f.data_ptr() for f in frames}) == 3
+    for i in (6, 7, 8):   # the last frame of every slot
+        ref, _ = oracle.render(fs, cams[i], w, h, max_depth=depth)
+        assert_parity(frames[i].cpu().numpy(), ref, f"frame {i} of three in flight")
+    with pytest.raises(RtError):
+        ctxs[0].set_device_share(0)
+    for c in ctxs:
+        c.close()

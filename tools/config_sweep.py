@@ -134,6 +134,38 @@ def main():
                               "shade_ms": [round(st["shade_ms"], 3) for _, st in res],
                               "rays": [rays_of(st) for _, st in res],
                               "efficiency_if_no_gather": round(full_ms / (G * max(ms)), 4)}), flush=True)
+    if "pipe" in want:
+        # Frames in flight: part 0 of G interleaved parts of the frame (what one rank of G renders),
+        # rendered back to back by 1, 2, 3 contexts taking turns, each on a stream of its own and
+        # sized for its share of the device.  ms per frame = wall time / frames.
+        flat = scene_1k().flatten()
+        (w, h), depth = (int(v) for v in args.split_size.split("x")), 4
+        for G in (8, 4, 2, 1):
+            rows = (h + G - 1) // G + 16
+            for n_ctx, share in ((1, 1), (2, 1), (2, 2), (3, 3), (4, 4)):
+                ctxs = [RenderContext([0]) for _ in range(n_ctx)]
+                streams = [torch.cuda.Stream() for _ in range(n_ctx)]
+                bufs = [torch.empty((rows, w), dtype=torch.int32, device="cuda") for _ in range(n_ctx)]
+                for c in ctxs:
+                    c.set_scene(flat)
+                    c.set_device_share(share)
+                n = args.frames * 8
+
+                def run(count):
+                    for i in range(count):
+                        k = i % n_ctx
+                        ctxs[k].render_bands_device(cam, w, h, 16, 0, G, depth, bufs[k].data_ptr(), streams[k].cuda_stream)
+                    torch.cuda.synchronize()
+
+                run(2 * n_ctx)
+                t0 = time.perf_counter()
+                run(n)
+                ms = (time.perf_counter() - t0) / n * 1e3
+                for c in ctxs:
+                    c.frame_status()
+                    c.close()
+                print(json.dumps({"config": f"{w}x{h}, part 0 of {G} interleaved parts, {n_ctx} contexts in turn, "
+                                            f"device share {share}", "ms_per_frame": round(ms, 4)}), flush=True)
     ctx.close()
 
 
