@@ -219,7 +219,7 @@ def main() -> None:
 
     keys = ("rays_primary", "rays_shadow", "rays_secondary", "shaded_hits", "sphere_tests",
             "plane_tests", "triangle_tests", "filter_ray_tests", "filter_origin_terms", "exact_candidates",
-            "primary_filter_ray_tests", "primary_exact_candidates")
+            "primary_filter_ray_tests", "primary_exact_candidates", "shadow_candidates")
     totals = torch.tensor([float(st[k]) for k in keys], dtype=torch.float64, device="cuda")
     times = torch.tensor([elapsed, ev["trace_ms"], ev["kernel_ms"], ev["primary_ms"], ev["shade_ms"], stalled],
                          dtype=torch.float64, device="cuda")
@@ -244,14 +244,15 @@ def main() -> None:
         tr_p = tot["plane_tests"] - tot["rays_primary"] * npl
         tr_t = tot["triangle_tests"] - tot["rays_primary"] * nt
         algorithmic_flop = FLOP_SPHERE * tr_s + FLOP_PLANE * tr_p + FLOP_TRIANGLE * tr_t
-        # What the traversal kernel executed: filter evaluations (4 FMA per ray and entry, 3 FMA +
-        # 1 subtraction per origin and entry), the exact Intersect of the candidates (36 FLOP per
-        # ray; a record has rays_per_record rays on average) and the plane / triangle tests.
+        # What the traversal kernel executed.  Reflection rays: filter evaluations against spheres
+        # and bounding balls (4 FMA per ray and entry, 3 FMA + 1 subtraction per origin and entry)
+        # and the exact Intersect of the candidates (25 FLOP to the discriminant + 11 to the hit).
+        # Light rays: the exact Intersect of every sphere their light's direction table lists
+        # (25 FLOP to the discriminant; few go on).  Plane / triangle tests as the reference makes them.
         tr_filter_rays = tot["filter_ray_tests"] - tot["primary_filter_ray_tests"]
         tr_candidates = tot["exact_candidates"] - tot["primary_exact_candidates"]
-        rays_per_record = (tot["rays_shadow"] + tot["rays_secondary"]) / max(tot["shaded_hits"], 1.0)
         executed_flop = (8.0 * tr_filter_rays + 7.0 * tot["filter_origin_terms"] +
-                         (FLOP_SPHERE + 11.0) * rays_per_record * tr_candidates +
+                         (FLOP_SPHERE + 11.0) * tr_candidates + FLOP_SPHERE * tot["shadow_candidates"] +
                          FLOP_PLANE * tr_p + FLOP_TRIANGLE * tr_t)
         trace_s = trace_ms * 1e-3
         # Per-GPU rate of the dominant kernel: each rank traced 1/world of the FLOP.
@@ -300,7 +301,8 @@ def main() -> None:
                 "algorithmic_tflops": round(algorithmic, 3),
                 "algorithmic_flop_per_launch": algorithmic_flop / world,
                 "algorithmic_speedup": round(algorithmic_flop / executed_flop, 3) if executed_flop > 0 else None,
-                "filter_ray_tests": int(tr_filter_rays), "algorithmic_sphere_tests": int(tr_s),
+                "filter_ray_tests": int(tr_filter_rays), "shadow_candidates": int(tot["shadow_candidates"]),
+                "reflection_candidates": int(tr_candidates), "algorithmic_sphere_tests": int(tr_s),
                 "frame": {"pipeline_ms": round(kernel_ms, 4), "primary_ms": round(primary_ms, 4),
                           "shade_ms": round(shade_ms, 4)},
             },

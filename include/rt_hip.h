@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RT_API_VERSION 4
+#define RT_API_VERSION 5
 
 /* Primitive type codes — the reference's own flatten uses exactly these
  * (MyApplication.cs:161,166,173). */
@@ -136,6 +136,9 @@ typedef struct rt_stats {
                                   per-origin term was formed (secondary and shadow rays)    */
     uint64_t primary_filter_ray_tests; /* the primary rays' share of filter_ray_tests ...   */
     uint64_t primary_exact_candidates; /* ... and of exact_candidates                        */
+    uint64_t shadow_candidates; /* (light ray, sphere) pairs evaluated with the exact Intersect code
+                                  out of the per-light direction tables: what light rays cost
+                                  in place of their sphere_tests                            */
     double   kernel_ms;
     double   primary_ms;
     double   trace_ms;

@@ -79,6 +79,7 @@ class rt_stats(C.Structure):
         ("filter_origin_terms", C.c_uint64),
         ("primary_filter_ray_tests", C.c_uint64),
         ("primary_exact_candidates", C.c_uint64),
+        ("shadow_candidates", C.c_uint64),
         ("kernel_ms", C.c_double),
         ("primary_ms", C.c_double),
         ("trace_ms", C.c_double),

@@ -19,7 +19,9 @@
 #include <exception>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 // Scratch of rt_render_rows_device_noalloc, the entry point that allocates nothing: the ray
@@ -37,8 +39,6 @@ constexpr int RT_SCRATCH_TABLE = 64;
 std::mutex g_scratch_lock;
 unsigned char *g_scratch_address[RT_SCRATCH_TABLE] = {};
 
-// Below this many level-0 tiles per resident workgroup a frame is bound by its chain of levels.
-constexpr int RT_CHAIN_BOUND_TILES_PER_WORKGROUP = 8;
 constexpr int RT_CHAIN_RESERVED_TILES_PER_WORKGROUP = 6;
 
 // Counter slots + level schedule + two record counts per level (DevFrame::counters, sched, cnt).
@@ -256,6 +256,12 @@ struct PackedScene {
     uint32_t textures_used = 0;
     float sph_center[3] = {0.f, 0.f, 0.f};
     float sph_l1max = 0.f, sph_sc = 0.f, grp_rmax = 0.f, sup_rmax = 0.f, chk_rmax = 0.f;
+    // Per-light direction tables (build_light_tables).
+    std::vector<uint2> lt_cells;
+    std::vector<float4> lt_sph;
+    std::vector<int> lt_orig;
+    int lt_n = 0;
+    float lt_near = 0.f;
 };
 
 bool usable_sphere(const float4 &s)
@@ -409,6 +415,209 @@ void build_filter_arrays(PackedScene &out)
     out.chk_rmax = (float)(chrmax * up);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Per-light direction tables: which spheres can occlude a light ray.
+//
+// Every light ray (IsInShadow, MyApplication.cs:370-380, called from objects.cs:56) ends at one
+// of a few fixed points, the lights.  Seen from a light L, sphere i covers a cap of directions;
+// a ray from a hit point h towards L can only meet sphere i if the direction of h - L lies in
+// that cap.  So per light the directions are cut into bins (a cube map: six faces of n x n
+// bins, face = largest component of h - L, (u, v) = the other two divided by it) and every bin
+// lists the spheres whose cap touches it; the kernel looks up the bin of h - L and runs the
+// exact, literal Sphere.Intersect over that short list instead of walking the scene.
+//
+// The lists are conservative against everything the reference's FP32 evaluation can do.  With
+// u = 2^-24, ray origin o = h and B >= |o - p_i| (rt_kernels.hip, "Sphere filter" and "Bounding
+// balls"): if the reference accepts (ray, sphere i) then the ray's exact line passes within
+//   R_i = sqrt(r_i^2 + 28.6u * B^2)
+// of p_i, and the point e = o + t*d at the reference's own t (0 < t < distance, as it demands)
+// lies within zeta = 8u * B of the part of the line inside that ball.  With the ray's direction
+// d = fl(normalize(L - o)) and distance = fl(|L - o|), o + distance * d misses L by at most
+// 4e-7 * |L - o|.  Hence either e is within m of L, and then |p_i - L| <= R_i + zeta + m + 4e-7
+// * Dmax (such a sphere is listed in EVERY bin), or the direction of e - L, which is within
+// asin((R_i + zeta) / |p_i - L|) of the direction of p_i - L, is within 4e-7 * Dmax / m + 2e-6 of
+// the direction of o - L.  The tables are built for origins with |o - centre|_1 <= near (the
+// kernel checks it per ray and evaluates the other rays against every sphere): B = near +
+// max |p'|_1, Dmax = near + |L - centre|_1, m = 4e-3 * Dmax, and every cap is widened by 2e-4
+// rad, which covers the 1e-4 above, the rounding of (u, v) on the device (< 1e-6) and the
+// double arithmetic here.
+// ---------------------------------------------------------------------------------------
+struct ConeNode {
+    double cx, cy, cz, cosb, sinb;   // centre direction (face-local: u, v, axis) and angular radius of a uv square
+};
+
+// Bounding cones of the quadtree over one cube face, level by level down to n x n leaves:
+// node (level, i, j) covers u in [-1 + 2i/2^level, -1 + 2(i+1)/2^level], v likewise.  The largest
+// angle between the centre and a direction of the square is at a corner (a cap is convex under
+// the gnomonic projection).
+std::vector<std::vector<ConeNode>> face_cones(int n)
+{
+    std::vector<std::vector<ConeNode>> levels;
+    for (int side = 1; side <= n; side *= 2) {
+        std::vector<ConeNode> nodes((size_t)side * side);
+        const double w = 2.0 / side;
+        for (int j = 0; j < side; j++)
+            for (int i = 0; i < side; i++) {
+                const double u0 = -1.0 + w * i, v0 = -1.0 + w * j, uc = u0 + 0.5 * w, vc = v0 + 0.5 * w;
+                const double len = std::sqrt(uc * uc + vc * vc + 1.0);
+                ConeNode nd{uc / len, vc / len, 1.0 / len, 1.0, 0.0};
+                double cosb = 1.0;
+                for (int k = 0; k < 4; k++) {
+                    const double u = u0 + (k & 1) * w, v = v0 + (k >> 1) * w;
+                    cosb = std::min(cosb, (nd.cx * u + nd.cy * v + nd.cz) / std::sqrt(u * u + v * v + 1.0));
+                }
+                cosb = std::max(-1.0, std::min(1.0, cosb)) * (1.0 - 1e-12) - 1e-12;   // rounded towards a wider cone
+                nd.cosb = cosb;
+                nd.sinb = std::sqrt(std::max(0.0, 1.0 - cosb * cosb)) * (1.0 + 1e-12) + 1e-12;
+                nodes[(size_t)j * side + i] = nd;
+            }
+        levels.push_back(std::move(nodes));
+    }
+    return levels;
+}
+
+int light_table_bins(size_t spheres)
+{
+    static const char *env = getenv("RT_HIP_LIGHT_BINS");   // tuning aid: bins per face edge (a power of two)
+    if (env && atoi(env) >= 1) {
+        int n = 1;
+        while (n < atoi(env) && n < 1024) n *= 2;
+        return n;
+    }
+    return spheres <= 256 ? 32 : spheres <= 4096 ? 64 : spheres <= 16384 ? 128 : 256;
+}
+
+void build_light_tables(PackedScene &out)
+{
+    const size_t ns = out.sph.size(), nl = out.light_pos.size();
+    out.lt_cells.clear();
+    out.lt_sph.clear();
+    out.lt_orig.clear();
+    out.lt_n = 0;
+    out.lt_near = 0.f;
+    if (ns == 0 || nl == 0) return;
+    const int n = light_table_bins(ns);
+    const double u24 = 1.0 / 16777216.0;
+    double cen[3] = {out.sph_center[0], out.sph_center[1], out.sph_center[2]};
+    double light_l1 = 0.0;
+    for (const float4 &lp : out.light_pos) {
+        const double l1 = std::fabs(lp.x - cen[0]) + std::fabs(lp.y - cen[1]) + std::fabs(lp.z - cen[2]);
+        if (std::isfinite(l1)) light_l1 = std::max(light_l1, l1);
+    }
+    // Origins the tables serve: twice the spheres' extent around their centre, and at least as
+    // far out as the lights.
+    const double near = 2.0 * std::max((double)out.sph_l1max, light_l1);
+    const double B = near + (double)out.sph_l1max;
+    const double s2 = 28.6 * u24 * B * B, zeta = 8.0 * u24 * B;
+    const auto cones = face_cones(n);
+    const int leaf_level = (int)cones.size() - 1;
+    const size_t cells_per_light = (size_t)6 * n * n;
+    out.lt_cells.assign(nl * cells_per_light, uint2{0u, 0u});
+
+    struct PerLight {
+        std::vector<uint32_t> cell, sphere;   // (bin, sphere) pairs in the order found
+        bool failed = false;
+    };
+    std::vector<PerLight> per(nl);
+    auto one_light = [&](size_t l) {
+        try {
+            PerLight &pl = per[l];
+            const float4 lp = out.light_pos[l];
+            const double L[3] = {lp.x, lp.y, lp.z};
+            const double Dmax = near + std::fabs(L[0] - cen[0]) + std::fabs(L[1] - cen[1]) + std::fabs(L[2] - cen[2]);
+            const double m = 4e-3 * Dmax, dl = 4e-7 * Dmax;
+            std::vector<uint32_t> stack;
+            for (size_t i = 0; i < ns; i++) {
+                const float4 &sp = out.sph[i];
+                if (!usable_sphere(sp)) continue;
+                const double R = (std::sqrt((double)sp.w + s2) + zeta) * (1.0 + 1e-9);
+                const double dx = sp.x - L[0], dy = sp.y - L[1], dz = sp.z - L[2];
+                const double dist = std::sqrt(dx * dx + dy * dy + dz * dz);
+                double cosa = 1.0, sina = 0.0;
+                bool everywhere = !(dist > R + m + dl) || !std::isfinite(dist);
+                if (!everywhere) {
+                    const double alpha = std::asin(std::min(1.0, R / dist)) + 2e-4;
+                    if (alpha >= 1.5) everywhere = true;
+                    cosa = std::cos(alpha), sina = std::sin(alpha);
+                }
+                const double vdir[3] = {dx / dist, dy / dist, dz / dist};
+                for (int face = 0; face < 6; face++) {
+                    // face-local coordinates: (u, v, axis) with the axis component positive on the face
+                    const int axis = face >> 1, ua = (axis + 1) % 3, va = (axis + 2) % 3;
+                    const double sgn = (face & 1) ? -1.0 : 1.0;
+                    const double a = everywhere ? 0.0 : vdir[ua] * sgn, b = everywhere ? 0.0 : vdir[va] * sgn,
+                                 w = everywhere ? 0.0 : vdir[axis] * sgn;
+                    stack.clear();
+                    stack.push_back(0u);   // (level << 24) | node index does not fit for n = 1024: two words
+                    stack.push_back(0u);
+                    while (!stack.empty()) {
+                        const uint32_t idx = stack.back();
+                        stack.pop_back();
+                        const uint32_t lv = stack.back();
+                        stack.pop_back();
+                        const ConeNode &nd = cones[lv][idx];
+                        if (!everywhere) {
+                            // reject when the angle between the cap's axis and the node's centre exceeds alpha + beta
+                            const double c = nd.cx * a + nd.cy * b + nd.cz * w;
+                            // (alpha <= 1.5 and beta <= 0.96 rad: the sum stays below pi, where cos decreases)
+                            const double cos_sum = cosa * nd.cosb - sina * nd.sinb;   // cos(alpha + beta)
+                            if (c < cos_sum - 1e-12) continue;
+                        }
+                        const uint32_t side = 1u << lv, i0 = idx % side, j0 = idx / side;
+                        if ((int)lv == leaf_level) {
+                            pl.cell.push_back((uint32_t)face * (uint32_t)(n * n) + idx);
+                            pl.sphere.push_back((uint32_t)i);
+                        } else {
+                            for (uint32_t k = 0; k < 4; k++) {
+                                stack.push_back(lv + 1);
+                                stack.push_back((2 * j0 + (k >> 1)) * (2 * side) + 2 * i0 + (k & 1));
+                            }
+                        }
+                    }
+                }
+            }
+        } catch (...) {
+            per[l].failed = true;
+        }
+    };
+    // One host thread per light, a few at a time.
+    const size_t workers = std::max<size_t>(1, std::min<size_t>({nl, (size_t)std::thread::hardware_concurrency(), 16}));
+    for (size_t l0 = 0; l0 < nl; l0 += workers) {
+        std::vector<std::thread> pool;
+        for (size_t l = l0; l < std::min(nl, l0 + workers); l++) pool.emplace_back(one_light, l);
+        for (std::thread &t : pool) t.join();
+    }
+    for (const PerLight &pl : per)
+        if (pl.failed) throw std::bad_alloc();
+    size_t total = 0;
+    for (const PerLight &pl : per) total += pl.cell.size();
+    if (total >= (size_t)1 << 31) throw std::length_error("the per-light occluder lists exceed 2^31 entries");
+    out.lt_sph.resize(total);
+    out.lt_orig.resize(total);
+    size_t base = 0;
+    for (size_t l = 0; l < nl; l++) {
+        const PerLight &pl = per[l];
+        uint2 *cells = out.lt_cells.data() + l * cells_per_light;
+        for (uint32_t c : pl.cell) cells[c].y++;
+        size_t off = base;
+        for (size_t c = 0; c < cells_per_light; c++) {
+            cells[c].x = (uint32_t)off;
+            off += cells[c].y;
+            cells[c].y = 0;
+        }
+        for (size_t k = 0; k < pl.cell.size(); k++) {
+            uint2 &c = cells[pl.cell[k]];
+            out.lt_sph[(size_t)c.x + c.y] = out.sph[pl.sphere[k]];
+            out.lt_orig[(size_t)c.x + c.y] = out.sph_orig[pl.sphere[k]];
+            c.y++;
+        }
+        base = off;
+    }
+    out.lt_n = n;
+    out.lt_near = (float)(near * (1.0 - 1e-6));
+}
+
 int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
 {
     const int n = s->num_prims, nl = s->num_lights;
@@ -483,6 +692,7 @@ int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
         out.light_pos[l] = make_float4(p[0], p[1], p[2], 0.f);
         out.light_col[l] = make_float4(c[0], c[1], c[2], c[3]);
     }
+    build_light_tables(out);
     return RT_OK;
 }
 
@@ -515,6 +725,11 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     if ((rc = upload(ctx, d, ps.light_pos, &sc.light_pos)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.light_col, &sc.light_col)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.class_prefix, &sc.class_prefix)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.lt_cells, &sc.lt_cells)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.lt_sph, &sc.lt_sph)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.lt_orig, &sc.lt_orig)) != RT_OK) return rc;
+    sc.lt_n = ps.lt_n;
+    sc.lt_near = ps.lt_near;
     sc.nsup_padded = (int)ps.sup_f.size();
     sc.nchk_padded = (int)ps.chk_f.size();
     sc.grp_rmax = ps.grp_rmax;
@@ -677,7 +892,6 @@ int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
     d.frame.slots = (int)slots;
     d.frame.max_depth = max_depth;
     d.frame.mask_words = words;
-    d.frame.first_lights = nl >= 4 ? 3 : 2;
     return RT_OK;
 }
 
@@ -781,14 +995,6 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // full-size launches would run one after the other instead of side by side.
     const int share = std::max(1, ctx->share);
     const int resident_plain = std::max(d.num_cus / 2, resident(false) / share);
-    // The walk that carries a record's reflection ray is the one the next level waits for.
-    // With plenty of tiles per resident workgroup the chain of levels hides behind the other
-    // work and the ray shares its walk with the first lights (fewest instructions); on a small
-    // frame the chain IS the frame time and the ray walks alone (shortest chain).
-    static const char *first_env = getenv("RT_HIP_FIRST_LIGHTS");
-    const int shared_walk = d.scene.nl >= 4 ? 3 : 2;
-    fr.first_lights = tiles0 >= RT_CHAIN_BOUND_TILES_PER_WORKGROUP * resident_plain ? shared_walk : 0;
-    if (first_env) fr.first_lights = std::max(0, std::min(atoi(first_env), shared_walk));
     fr.any_hit = counting ? 0 : 1;
     // On still smaller frames (measured: below ~6 tiles per resident workgroup; 4K / 8 GPUs has 4)
     // it pays to reserve the oldest workgroup of every compute unit for the chain: a SIMD issues
@@ -1473,6 +1679,7 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out)
         out->filter_origin_terms += c.filter_origin_terms;
         out->primary_filter_ray_tests += c.primary_filter_ray_tests;
         out->primary_exact_candidates += c.primary_exact_candidates;
+        out->shadow_candidates += c.shadow_candidates;
         if (d.timed) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, d.ev[0], d.ev[3]) == hipSuccess) kernel_ms = std::max(kernel_ms, (double)ms);

@@ -75,6 +75,16 @@ struct DevScene {
     // class_prefix[3*i + c] = number of primitives of class c among host primitives
     // [0, i): lets a kernel turn "first occluder index" into per-class test counts.
     const int *class_prefix;
+    // Per-light direction tables (rt_api.cpp, build_light_tables): for light l and the cube-map bin
+    // of the direction from the light to a ray's origin, lt_cells[(l * 6 + face) * lt_n * lt_n + v * lt_n
+    // + u] = {first entry, entries} of the spheres that can occlude such a ray: lt_sph {centre, r*r}
+    // and lt_orig (host primitive index) per entry.  Valid for origins with |o - sph_center|_1 <=
+    // lt_near; lt_n = 0: no tables (no spheres or no lights).
+    const uint2 *lt_cells;
+    const float4 *lt_sph;
+    const int *lt_orig;
+    int lt_n;
+    float lt_near;
     const uchar4 *tex[RT_DEV_MAX_TEXTURES];
     int tex_w[RT_DEV_MAX_TEXTURES];
     int tex_h[RT_DEV_MAX_TEXTURES];
@@ -112,6 +122,7 @@ struct DevCounters {
     unsigned long long filter_origin_terms;   // (origin, sphere or ball) per-origin terms formed
     unsigned long long primary_filter_ray_tests;   // the primary kernel's share of filter_ray_tests
     unsigned long long primary_exact_candidates;   // ... and of exact_candidates
+    unsigned long long shadow_candidates;   // (light ray, sphere) pairs evaluated exactly from the lights' tables
 };
 
 // Tile schedule of k_trace_levels (rt_kernels.hip), zeroed before every render call.
@@ -158,7 +169,6 @@ struct DevFrame {
     int slots;             // P * (max_depth + 1)
     int max_depth;
     int mask_words;        // ceil(nl / 32), at least 1
-    int first_lights;      // lights traced in the same walk as a record's reflection ray (rt_kernels.hip, walks_of)
     int any_hit;           // 1: a light ray may stop at ANY occluder (the Intersect-call counters are not wanted)
     int chain_policy;      // 1: k_trace_levels keeps the tiles the next level waits for to the workgroups that
                            // arrived first on their compute units, and the first of each free for them

@@ -11,9 +11,9 @@
 // Pipeline per frame (one HIP stream, in order):
 //   setup_camera   per sphere: the filter's per-sphere term for the camera origin
 //   primary        per pixel: ray direction, closest hit -> level-0 hit record
-//   trace_level k  per hit record: its light rays (any-hit) and, if the surface is
-//                  specular and k < max_depth, its reflection ray (closest hit) walk the
-//                  scene ONCE together, sharing the origin-dependent terms
+//   trace_level k  per hit record: if the surface is specular and k < max_depth, its
+//                  reflection ray (closest hit) walks the scene; its light rays (any-hit)
+//                  look up the spheres that can occlude them in per-light direction tables
 //   shade_level k  (k = max_depth .. 0) Primitive.Shade for every record of the level;
 //                  the colour goes to the parent record or, at level 0, to the pixel
 // The per-pixel bounce stack lives in HBM as compacted per-level queues (rt_device.h),
@@ -206,50 +206,6 @@ __device__ __forceinline__ void store_record(float4 *dst, const f4raw v)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
 }
 
-// The rays of a hit record are traced in one or more WALKS of the scene, each a job of its own
-// for the level schedule: at most LCMAX rays per walk, where LCMAX = 4 in scenes with four or
-// more lights and 2 otherwise (with few lights the two-ray instance needs far fewer registers
-// and its rays are close enough to share one selection of spheres).  Walk 0 of a reflecting
-// record carries the reflection ray and its first `first` lights (DevFrame::first_lights: LCMAX - 1,
-// with LCMAX 2 both lights, i.e. three rays; or 0, which makes the walk that has successors as
-// short as possible); the other walks take the remaining lights in aligned groups of LCMAX,
-// after one short walk up to the first multiple of LCMAX if need be.  A walk's lights never
-// straddle a 32-bit word of the occlusion mask.
-__host__ __device__ __forceinline__ int walk_lcmax(int nl) { return nl >= 4 ? 4 : 2; }
-__host__ __device__ __forceinline__ int walks_of(bool reflecting, int nl, int first)
-{
-    const int g = walk_lcmax(nl), f = first;
-    if (!reflecting) return (nl + g - 1) / g;
-    if (nl <= f) return 1;
-    const int a0 = (f + g - 1) / g * g;
-    return 1 + (a0 > f ? 1 : 0) + (nl > a0 ? (nl - a0 + g - 1) / g : 0);
-}
-__device__ __forceinline__ void walk_lights(bool reflecting, int walk, int nl, int first, int &l0, int &count)
-{
-    const int g = walk_lcmax(nl), f = first;
-    if (!reflecting) {
-        l0 = walk * g;
-        count = min(g, nl - l0);
-        return;
-    }
-    if (walk == 0) {
-        l0 = 0;
-        count = min(f, nl);
-        return;
-    }
-    const int a0 = (f + g - 1) / g * g;
-    if (a0 > f) {
-        if (walk == 1) {
-            l0 = f;
-            count = min(a0, nl) - f;
-            return;
-        }
-        walk--;
-    }
-    l0 = a0 + (walk - 1) * g;
-    count = min(g, nl - l0);
-}
-
 // A 32-bit word to memory with a device-scope store, like store_record.
 __device__ __forceinline__ void store_word_through(uint32_t *dst, uint32_t v)
 {
@@ -329,12 +285,6 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
                 f.recA[slot] = make_float4(hit[k].x, hit[k].y, hit[k].z, __int_as_float(prim[k]));
                 f.recB[slot] = make_float4(view[k].x, view[k].y, view[k].z, __int_as_float(parent[k]));
             }
-            // Several walks OR their lights into the record's occlusion words: start from zero.
-            if (walks_of(is_a[k], s.nl, f.first_lights) > 1)
-                for (int w = 0; w < f.mask_words; w++) {
-                    if (THROUGH) store_word_through(&f.mask[(size_t)w * (size_t)f.slots + slot], 0u);
-                    else f.mask[(size_t)w * (size_t)f.slots + slot] = 0u;
-                }
         }
     }
     __syncthreads();  // blk may be reused by the caller's next trip
@@ -1069,18 +1019,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     // Counter words in the order of DevCounters; the filter's counts are the same in every lane.
     const unsigned long long cand_total = (unsigned long long)wave_sum(fw.candidates);
     const unsigned long long tests = 64ull * (unsigned long long)fw.ray_tests;
-    const unsigned long long v[COUNTER_WORDS] = {0ull, 0ull, 0ull, cand_total, tests, 0ull, tests, cand_total};
+    const unsigned long long v[COUNTER_WORDS] = {0ull, 0ull, 0ull, cand_total, tests, 0ull, tests, cand_total, 0ull};
 #ifndef RT_PHASE_CLOCKS
     flush_counters(f, cnt_sh, v);
 #endif
 }
 
 // ---------------------------------------------------------------------------------------
-// trace_level: for each hit record, IsInShadow towards every light (objects.cs:51-60)
-// and, for specular surfaces below the depth bound, scene.Intersect along the mirror
-// direction (objects.cs:82-83).  All of a record's rays start at its hit point, so
-// the filter's per-sphere term is formed once per sphere and shared by the record's NR rays:
-// a sphere costs 4 + 4*NR full-rate instructions per lane plus one per two or three rays.
+// trace_level: for each hit record, for specular surfaces below the depth bound,
+// scene.Intersect along the mirror direction (objects.cs:82-83) — a walk of the scene through
+// the filter loops — and IsInShadow towards every light (objects.cs:51-60) through the lights'
+// direction tables (trace_lights below).
 // ---------------------------------------------------------------------------------------
 // Per-lane work counters of a kernel.
 struct TestCount {
@@ -1088,6 +1037,7 @@ struct TestCount {
     int exact;        // (record, sphere) pairs this lane evaluated exactly
     int filt_terms;   // spheres and balls this lane formed the filter's per-origin term for
     int filt_rays;    // (ray, sphere or ball) pairs this lane's filter evaluated
+    int shadow;       // (light ray, sphere) pairs this lane evaluated exactly from the lights' tables
 };
 
 template <int LC, bool SEC>
@@ -1220,60 +1170,151 @@ __device__ __forceinline__ f3 record_normal(const DevScene &s, int prim, int typ
 }
 
 
-// One chunk of LC lights (plus the reflection ray when SEC) for one record.
-template <int LC, bool SEC, bool SPLIT, bool MULTI>
-__device__ __forceinline__ void trace_chunk(const DevScene &s, WalkLds &L, const f3 hit,
-                                            const f3 view, const f3 normal, int l0, uint32_t &mask_word,
-                                            Closest &sec_out, f3 &sec_dir, TestCount &tc, PhaseClock &pc,
-                                            const bool any_hit)
+// A record's reflection ray (objects.cs:82-83): closest hit over the whole scene.
+template <bool MULTI>
+__device__ __forceinline__ void trace_reflection(const DevScene &s, WalkLds &L, const f3 hit, const f3 view,
+                                                 const f3 normal, Closest &sec_out, f3 &sec_dir, TestCount &tc,
+                                                 PhaseClock &pc)
 {
-    Rays<LC, SEC> r;
-#pragma unroll
-    for (int l = 0; l < LC; l++) {
-        const f3 lp = xyz(cload(s.light_pos, l0 + l));
+    Rays<0, true> r;
+    // objects.cs:82: (viewDir - 2 * Dot(viewDir, normal) * normal).Normalized()
+    r.sec_d = normalized3(sub3(view, scale3(normal, 2.0f * dot3(view, normal))));
+    r.sec_a = dot3(r.sec_d, r.sec_d);
+    r.sec.t = RT_FLT_MAX;
+    r.sec.prim = INT_MAX;
+    traverse<0, true, false, MULTI>(s, L, hit, r, tc, pc, true);
+    sec_out = r.sec;
+    sec_dir = r.sec_d;
+    tc.sph += s.ns;
+    tc.pl += s.np;
+    tc.tri += s.nt;
+}
+
+// ---------------------------------------------------------------------------------------
+// Light rays (IsInShadow, MyApplication.cs:370-380, called once per light from objects.cs:56).
+// Every light ray ends at a light, so the spheres that can occlude it are found in that light's
+// direction table (rt_device.h, DevScene::lt_cells; built and proven conservative in rt_api.cpp,
+// build_light_tables): the bin of the direction from the light to the ray's origin lists them,
+// and the literal Sphere.Intersect runs over that list.  Origins farther from the scene than the
+// tables were built for evaluate every sphere.  Planes and triangles are few and tested one by
+// one as the reference does.
+// ---------------------------------------------------------------------------------------
+
+// Cell of light l's table for the direction w (from the light to the ray's origin; any length).
+__device__ __forceinline__ uint2 light_table_cell(const DevScene &s, const int l, const f3 w)
+{
+    const float ax = fabsf(w.x), ay = fabsf(w.y), az = fabsf(w.z);
+    int axis;
+    float m, a, b;   // major component, then the two others in cyclic order
+    if (ax >= ay && ax >= az) axis = 0, m = w.x, a = w.y, b = w.z;
+    else if (ay >= az) axis = 1, m = w.y, a = w.z, b = w.x;
+    else axis = 2, m = w.z, a = w.x, b = w.y;
+    const int face = 2 * axis + (m < 0.0f ? 1 : 0);
+    const float inv = __builtin_amdgcn_rcpf(m);   // 1 ulp: far inside the tables' angular margin
+    const float half = 0.5f * (float)s.lt_n;
+    const float fu = (a * inv + 1.0f) * half, fv = (b * inv + 1.0f) * half;
+    const int top = s.lt_n - 1;
+    const int iu = !(fu >= 0.0f) ? 0 : (fu >= (float)top ? top : (int)fu);   // NaN -> 0
+    const int iv = !(fv >= 0.0f) ? 0 : (fv >= (float)top ? top : (int)fv);
+    return s.lt_cells[((size_t)(l * 6 + face) * (size_t)s.lt_n + (size_t)iv) * (size_t)s.lt_n + (size_t)iu];
+}
+
+// One light ray against one sphere, objects.cs:112-121 literally; true = an occluder in (eps, dist).
+__device__ __forceinline__ bool sphere_occludes(const float4 sp, const f3 o, const f3 d, const float a, const float dist)
+{
+    const f3 op = sub3(o, xyz(sp));
+    const float c = dot3(op, op) - sp.w;
+    const float x = dot3(d, op);
+    float t;
+    return sphere_maybe(x, a * c) && sphere_root(x, c, a, t) && t > RT_EPS && t < dist;
+}
+
+// The occlusion bits of a record's lights into DevFrame::mask.  COUNT: the reference's
+// Intersect-call counts are kept, which need the FIRST occluder in host order
+// (MyApplication.cs:373-378): every candidate is evaluated.  Otherwise a ray stops at any occluder.
+template <bool COUNT>
+__device__ __forceinline__ void trace_lights(const DevScene &s, const DevFrame &f, const f3 hit, const int slot,
+                                             const bool active, TestCount &tc)
+{
+    const int nl = s.nl;
+    const f3 oc = mk3(hit.x - s.sph_center[0], hit.y - s.sph_center[1], hit.z - s.sph_center[2]);
+    // (a NaN origin is "far" and then meets nothing, like in the reference)
+    const bool far = s.lt_n > 0 && !(((fabsf(oc.x) + fabsf(oc.y)) + fabsf(oc.z)) <= s.lt_near);
+    const bool any_far = s.lt_n > 0 && __ballot(far) != 0ull;
+    uint32_t word = 0;
+    for (int l = 0; l < nl; l++) {
+        const f3 lp = xyz(cload(s.light_pos, l));
         const f3 to_light = sub3(lp, hit);
-        r.sh_d[l] = normalized3(to_light);          // objects.cs:51
-        r.sh_dist[l] = length3(to_light);           // objects.cs:52
-        r.sh_a[l] = dot3(r.sh_d[l], r.sh_d[l]);
-        r.sh_first[l] = INT_MAX;
-    }
-    if (SEC) {
-        // objects.cs:82: (viewDir - 2 * Dot(viewDir, normal) * normal).Normalized()
-        r.sec_d = normalized3(sub3(view, scale3(normal, 2.0f * dot3(view, normal))));
-        r.sec_a = dot3(r.sec_d, r.sec_d);
-        r.sec.t = RT_FLT_MAX;
-        r.sec.prim = INT_MAX;
-    }
-    traverse<LC, SEC, SPLIT, MULTI>(s, L, hit, r, tc, pc, any_hit);
-    PHASE_MARK(pc, 6)
-#pragma unroll
-    for (int l = 0; l < LC; l++) {
-        const bool occluded = r.sh_first[l] != INT_MAX;
-        if (occluded) mask_word |= 1u << ((l0 + l) & 31);
-        // Tests the reference executes for this light: primitives up to and including
-        // the first occluder (MyApplication.cs:373-378), all of them when unoccluded.
-        const int upto = occluded ? r.sh_first[l] + 1 : s.nprims;
-        tc.sph += cload(s.class_prefix, 3 * upto + 0);
-        tc.pl += cload(s.class_prefix, 3 * upto + 1);
-        tc.tri += cload(s.class_prefix, 3 * upto + 2);
-    }
-    if (SEC) {
-        sec_out = r.sec;
-        sec_dir = r.sec_d;
-        tc.sph += s.ns;
-        tc.pl += s.np;
-        tc.tri += s.nt;
+        const f3 d = normalized3(to_light);          // objects.cs:51
+        const float dist = length3(to_light);        // objects.cs:52
+        const float a = dot3(d, d);
+        int first = INT_MAX;   // lowest host index among the occluders found
+        for (int j = 0; j < s.np; j++) {
+            const float4 pl = cload(s.pl, j);
+            const f3 n = xyz(pl);
+            float t;
+            if (plane_t(n, (-dot3(n, hit)) - pl.w, d, t) && t > RT_EPS && t < dist) first = min(first, cload(s.pl_orig, j));
+        }
+        for (int j = 0; j < s.nt; j++) {
+            const f3 v0 = xyz(cload(s.tri, 3 * j)), e1 = xyz(cload(s.tri, 3 * j + 1)), e2 = xyz(cload(s.tri, 3 * j + 2));
+            float t;
+            if (triangle_t(e1, e2, sub3(hit, v0), d, t) && t > RT_EPS && t < dist) first = min(first, cload(s.tri_orig, j));
+        }
+        if (s.lt_n > 0) {
+            uint2 cell = light_table_cell(s, l, sub3(hit, lp));
+            int cnt = far || (!COUNT && first != INT_MAX) ? 0 : (int)cell.y;
+            const float4 *list = s.lt_sph + cell.x;
+            float4 nxt = cnt > 0 ? list[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma clang loop unroll(disable)
+            for (int k = 0; __ballot(k < cnt) != 0ull; k++) {
+                const float4 sp = nxt;
+                if (k + 1 < cnt) nxt = list[k + 1];
+                if (k < cnt) {
+                    if (COUNT) tc.shadow++;
+                    if (sphere_occludes(sp, hit, d, a, dist)) {
+                        if (COUNT) first = min(first, s.lt_orig[cell.x + k]);
+                        else first = 0, cnt = 0;   // any occluder will do
+                    }
+                }
+            }
+            if (any_far) {   // origins the tables do not serve: every sphere
+                const int todo = far && (COUNT || first == INT_MAX) ? s.ns_padded : 0;
+#pragma clang loop unroll(disable)
+                for (int k = 0; __ballot(k < todo) != 0ull; k++) {
+                    if (k < todo) {
+                        if (COUNT) tc.shadow++;
+                        if (sphere_occludes(s.sph[k], hit, d, a, dist)) first = min(first, s.sph_orig[k]);
+                    }
+                }
+            }
+        }
+        const bool occluded = first != INT_MAX;
+        if (occluded) word |= 1u << (l & 31);
+        if (COUNT && active) {
+            // Tests the reference executes for this light: primitives up to and including
+            // the first occluder (MyApplication.cs:373-378), all of them when unoccluded.
+            const int upto = occluded ? first + 1 : s.nprims;
+            tc.sph += cload(s.class_prefix, 3 * upto + 0);
+            tc.pl += cload(s.class_prefix, 3 * upto + 1);
+            tc.tri += cload(s.class_prefix, 3 * upto + 2);
+        }
+        if ((l & 31) == 31 || l == nl - 1) {
+            if (active) f.mask[(size_t)(l >> 5) * (size_t)f.slots + slot] = word;   // the record's only writer
+            word = 0;
+        }
     }
 }
 
-// One walk of one tile = 256 consecutive records of one queue of one level, one record per
-// lane.  SEC: the records of the level that need a reflection trace (queue "A") or the others
-// ("B"); walk: which of the records' walks (walks_of).  LCMAX = walk_lcmax(lights of the scene).
-// n = records in the queue.  Every thread of the workgroup must call it (barriers inside).
-template <bool SEC, int LCMAX, bool MULTI>
+// One tile = 256 consecutive records of one queue of one level, one record per lane.  SEC: the
+// records of the level that need a reflection trace (queue "A") or the others ("B").  A records
+// first walk the scene with their reflection ray and push the records of the next level, then
+// after_push() runs (workgroup-uniform; the level schedule counts the tile there, so that the
+// next level opens before this tile's light rays are traced), then the light rays.  n = records in
+// the queue.  Every thread of the workgroup must call it (barriers inside).
+template <bool SEC, bool MULTI, bool COUNT, class AfterPush>
 __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f, WalkLds &L, int *blk,
-                                           const int level, const int tile, const int n, const int walk,
-                                           TestCount &tc, PhaseClock &pc)
+                                           const int level, const int tile, const int n,
+                                           TestCount &tc, PhaseClock &pc, AfterPush &&after_push)
 {
     PHASE_MARK(pc, 0)
     const int i = tile * 256 + threadIdx.x;
@@ -1282,56 +1323,25 @@ __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f,
     const int slot = SEC ? (level * f.P + ii) : ((level + 1) * f.P - 1 - ii);
     float4 ra, rb;
     load_record(&f.recA[slot], &f.recB[slot], ra, rb);
-    const f3 hit = xyz(ra), view = xyz(rb);
-    const int prim = __float_as_int(ra.w);
-    const int type = __float_as_int(cload(s.mat, 3 * prim + 1).w) & RT_MF_TYPE_MASK;
-    const f3 normal = record_normal(s, prim, type, hit);
-
-    Closest sec = {RT_FLT_MAX, INT_MAX};
-    f3 sec_dir = mk3(0.0f, 0.0f, 0.0f);
-    TestCount ltc = {0, 0, 0, 0, 0, 0};
-    uint32_t word = 0;
-    const int nl = s.nl;
-    const bool with_sec = SEC && walk == 0;
-    int l0, count;
-    walk_lights(SEC, walk, nl, f.first_lights, l0, count);
-#define RT_WALK(LC_, SEC_) trace_chunk<LC_, SEC_, (LCMAX >= 4), MULTI>(s, L, hit, view, normal, l0, word, sec, sec_dir, ltc, pc, f.any_hit != 0)
-    bool done = false;
-    if constexpr (LCMAX >= 4) {
-        if (count == 4) {   // never with the reflection ray: a walk has at most four rays
-            RT_WALK(4, false);
-            done = true;
-        } else if (count == 3) {
-            if (SEC && with_sec) RT_WALK(3, true);
-            else RT_WALK(3, false);
-            done = true;
+    const f3 hit = xyz(ra);
+    if constexpr (SEC) {
+        const f3 view = xyz(rb);
+        const int prim = __float_as_int(ra.w);
+        const int type = __float_as_int(cload(s.mat, 3 * prim + 1).w) & RT_MF_TYPE_MASK;
+        const f3 normal = record_normal(s, prim, type, hit);
+        Closest sec = {RT_FLT_MAX, INT_MAX};
+        f3 sec_dir = mk3(0.0f, 0.0f, 0.0f);
+        TestCount ltc = {0, 0, 0, 0, 0, 0, 0};
+        trace_reflection<MULTI>(s, L, hit, view, normal, sec, sec_dir, ltc, pc);
+        PHASE_MARK(pc, 6)
+        if (active) {
+            tc.sph += ltc.sph;
+            tc.pl += ltc.pl;
+            tc.tri += ltc.tri;
+            tc.exact += ltc.exact;
         }
-    }
-    if (done) {
-    } else if (count == 2) {
-        if (SEC && with_sec) RT_WALK(2, true);
-        else RT_WALK(2, false);
-    } else if (count == 1) {
-        if (SEC && with_sec) RT_WALK(1, true);
-        else RT_WALK(1, false);
-    } else if (SEC && with_sec) {
-        RT_WALK(0, true);
-    }
-#undef RT_WALK
-    if (active && count > 0) {
-        uint32_t *mw = &f.mask[(size_t)(l0 >> 5) * (size_t)f.slots + slot];
-        if (walks_of(SEC, nl, f.first_lights) == 1) *mw = word;   // the only writer of the record's (single) word
-        else if (word) atomicOr(mw, word);         // zeroed when the record was written
-    }
-    if (active) {
-        tc.sph += ltc.sph;
-        tc.pl += ltc.pl;
-        tc.tri += ltc.tri;
-        tc.exact += ltc.exact;
-    }
-    tc.filt_terms += ltc.filt_terms;   // inactive lanes run the loops too
-    tc.filt_rays += ltc.filt_rays;
-    if (SEC && with_sec) {   // workgroup-uniform
+        tc.filt_terms += ltc.filt_terms;   // inactive lanes run the loops too
+        tc.filt_rays += ltc.filt_rays;
         const bool child = active && sec.prim != INT_MAX;
         const f3 hit2 = add3(hit, scale3(sec_dir, sec.t));   // objects.cs:123,166,263
         if (active) f.refl[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1339,24 +1349,29 @@ __device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f,
         const int rp[1] = {child ? sec.prim : 0}, rparent[1] = {slot};
         const f3 rh[1] = {hit2}, rd[1] = {sec_dir};
         push_records<1>(f, s, level + 1, blk, rv, rp, rh, rd, rparent);
+        after_push();
     }
     PHASE_MARK(pc, 7)
+    trace_lights<COUNT>(s, f, hit, slot, active, tc);
+    PHASE_MARK(pc, 5)
 }
 
 __device__ __forceinline__ void flush_test_counts(const DevFrame &f, unsigned long long *cnt_sh, const TestCount &tc)
 {
-    static_assert(COUNTER_WORDS == 8, "the initialiser below follows DevCounters word for word");
-    const int ws = wave_sum(tc.sph), wp = wave_sum(tc.pl), wt = wave_sum(tc.tri), we = wave_sum(tc.exact);
+    static_assert(COUNTER_WORDS == 9, "the initialiser below follows DevCounters word for word");
+    const int ws = wave_sum(tc.sph), wp = wave_sum(tc.pl), wt = wave_sum(tc.tri), we = wave_sum(tc.exact),
+              wsh = wave_sum(tc.shadow);
     // the filter counts are the same in every lane of the wave
     const unsigned long long v[COUNTER_WORDS] = {(unsigned long long)ws, (unsigned long long)wp, (unsigned long long)wt,
                                                  (unsigned long long)we, 64ull * (unsigned long long)tc.filt_rays,
-                                                 64ull * (unsigned long long)tc.filt_terms, 0ull, 0ull};
+                                                 64ull * (unsigned long long)tc.filt_terms, 0ull, 0ull,
+                                                 (unsigned long long)wsh};
     flush_counters(f, cnt_sh, v);
 }
 
 // One queue of one level per launch (the form a kernel trace can attribute time to; the
 // frame pipeline normally uses k_trace_levels below).
-template <bool SEC, int LCMAX, bool MULTI>
+template <bool SEC, bool MULTI>
 __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level)
 {
     __shared__ WalkLds L;
@@ -1364,16 +1379,14 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int n = SEC ? f.cnt[2 * level] : f.cnt[2 * level + 1];
     const int ntiles = (n + 255) >> 8;
-    if (!MULTI && (int)blockIdx.x < ntiles) {
+    if (SEC && !MULTI && (int)blockIdx.x < ntiles) {
         stage_chunk<false>(L, s, FilterOrigin{}, 0, s.ns_padded);
         __syncthreads();
     }
-    TestCount tc = {0, 0, 0, 0, 0, 0};
+    TestCount tc = {0, 0, 0, 0, 0, 0, 0};
     PhaseClock pc = {};
-    // Workgroup-uniform trip count: the sphere chunks are staged between barriers.
-    const int walks = walks_of(SEC, s.nl, f.first_lights);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
-        for (int walk = 0; walk < walks; walk++) trace_tile<SEC, LCMAX, MULTI>(s, f, L, blk, level, tile, n, walk, tc, pc);
+        trace_tile<SEC, MULTI, true>(s, f, L, blk, level, tile, n, tc, pc, [] {});
     flush_test_counts(f, cnt_sh, tc);
 }
 
@@ -1398,8 +1411,8 @@ __global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level
 //   * a taker (thread 0) reads open_level with a device-scope load on every claim and reads a
 //     newly opened level's record counts before it hands tiles of that level to the workgroup.
 //     No cache invalidation is needed either: the records are read with device-scope loads
-//     (load_record), the occlusion words are zeroed with device-scope stores and updated with
-//     device-scope atomics, and the levels' slot ranges start at multiples of RT_LEVEL_ALIGN
+//     (load_record), a record's occlusion words have one writer (plain stores, read by the
+//     shading launches), and the levels' slot ranges start at multiples of RT_LEVEL_ALIGN
 //     slots, so no cache line of a per-slot array holds slots of two levels.
 // The chain ends at the first open level without A records (level max_depth never has any);
 // a workgroup leaves when the chain has ended and no B tile is left to claim.  A workgroup
@@ -1430,22 +1443,20 @@ struct Taker {
 // large frame in register pressure.
 // COUNT: the work counters of rt_stats are kept (profiling); without them the compiler drops
 // the per-lane sums and the per-light prefix lookups they are made of.
-template <int LCMAX, bool MULTI, bool RESERVE, bool COUNT>
+template <bool MULTI, bool RESERVE, bool COUNT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 k_trace_levels(DevScene s, DevFrame f)
 {
     __shared__ WalkLds L;
     __shared__ int blk[12];
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
-    __shared__ int job[5];
-    // Record counts of the seen levels and what is left to claim of their plain jobs (thread 0).
+    __shared__ int job[4];
+    // Record counts of the seen levels and what is left to claim of their plain tiles (thread 0).
     __shared__ int lv_a[RT_DEV_MAX_LEVELS], lv_b[RT_DEV_MAX_LEVELS], lv_jobs[RT_DEV_MAX_LEVELS];
     DevSched *const sc = f.sched;
     const int D = f.max_depth;
-    // Plain jobs of a level: every walk of its B tiles and the walks after the first of its A tiles.
-    const int walks_a = walks_of(true, s.nl, f.first_lights), walks_b = walks_of(false, s.nl, f.first_lights);
     bool staged = false;
-    TestCount tc = {0, 0, 0, 0, 0, 0};
+    TestCount tc = {0, 0, 0, 0, 0, 0, 0};
     PhaseClock pc = {};
 #ifdef RT_PHASE_CLOCKS
     pc.t_last = __builtin_readcyclecounter();
@@ -1464,7 +1475,7 @@ k_trace_levels(DevScene s, DevFrame f)
 #endif
     for (;;) {
         if (threadIdx.x == 0) {
-            int kind = SCHED_JOB_EXIT, lvl = 0, tile = 0, n = 0, walk = 0;
+            int kind = SCHED_JOB_EXIT, lvl = 0, tile = 0, n = 0;
             unsigned long long wait_since = 0ull;   // wall clock at the first idle poll of this wait
             for (;;) {
                 // What this workgroup believes is claimable, A tiles of the newest level first.
@@ -1503,25 +1514,15 @@ k_trace_levels(DevScene s, DevFrame f)
                     for (int k = tk.seen_open + 1; k <= open; k++) {
                         lv_a[k] = k < D ? sched_load(&f.cnt[2 * k]) : 0;
                         lv_b[k] = sched_load(&f.cnt[2 * k + 1]);
-                        const int jobs = ((lv_b[k] + 255) >> 8) * walks_b + ((lv_a[k] + 255) >> 8) * (walks_a - 1);
+                        const int jobs = (lv_b[k] + 255) >> 8;
                         lv_jobs[k] = jobs > 0 ? jobs : -1;   // -1: nothing (left) to claim
                     }
                     tk.seen_open = open;
                     tk.a_left = lv_a[open] > 0;
                 }
                 if (claimed) {
-                    kind = cand_kind, lvl = cand_lvl;
-                    if (kind == SCHED_JOB_A) {
-                        tile = t, n = lv_a[lvl], walk = 0;
-                    } else {
-                        const int plain = ((lv_b[lvl] + 255) >> 8) * walks_b;
-                        if (t < plain) {
-                            tile = t / walks_b, walk = t % walks_b, n = lv_b[lvl];
-                        } else {   // a later walk of a reflecting tile: no successors either
-                            kind = SCHED_JOB_A;
-                            tile = (t - plain) / (walks_a - 1), walk = 1 + (t - plain) % (walks_a - 1), n = lv_a[lvl];
-                        }
-                    }
+                    kind = cand_kind, lvl = cand_lvl, tile = t;
+                    n = kind == SCHED_JOB_A ? lv_a[lvl] : lv_b[lvl];
                     break;
                 }
                 if (ctr || opened) {
@@ -1546,36 +1547,36 @@ k_trace_levels(DevScene s, DevFrame f)
             job[1] = lvl;
             job[2] = tile;
             job[3] = n;
-            job[4] = walk;
         }
         __syncthreads();
-        const int kind = job[0], lvl = job[1], tile = job[2], n = job[3], walk = job[4];
+        const int kind = job[0], lvl = job[1], tile = job[2], n = job[3];
         if (kind == SCHED_JOB_EXIT) break;
-        if (!MULTI && !staged) {
+        // Only reflection rays walk the staged spheres: stage them before the first such tile.
+        if (!MULTI && !staged && kind == SCHED_JOB_A) {
             stage_chunk<false>(L, s, FilterOrigin{}, 0, s.ns_padded);
             staged = true;
         }
         __syncthreads();   // job[] read by all, spheres staged
-        if (kind == SCHED_JOB_A && walk == 0) {
+        if (kind == SCHED_JOB_A) {
             __builtin_amdgcn_s_setprio(3);   // the chain of levels is the launch's critical path
-            trace_tile<true, LCMAX, MULTI>(s, f, L, blk, lvl, tile, n, 0, tc, pc);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's record stores have reached memory
-            __builtin_amdgcn_s_setprio(0);
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const int tiles_a = (n + 255) >> 8;
-                // (debug_withhold: a test knob that loses one tile's count, so that the next level never opens)
-                if (!(lvl == f.debug_withhold && tile == 0) && atomicAdd(&sc->done_a[lvl], 1) + 1 == tiles_a) {
+            trace_tile<true, MULTI, COUNT>(s, f, L, blk, lvl, tile, n, tc, pc, [&] {
+                // The next level's records are pushed: count the tile before its light rays are traced.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's record stores have reached memory
+                __builtin_amdgcn_s_setprio(0);
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    const int tiles_a = (n + 255) >> 8;
+                    // (debug_withhold: a test knob that loses one tile's count, so that the next level never opens)
+                    if (!(lvl == f.debug_withhold && tile == 0) && atomicAdd(&sc->done_a[lvl], 1) + 1 == tiles_a) {
 #ifdef RT_SCHED_TIMELINE
-                    sc->t_open[lvl + 1] = (unsigned long long)wall_clock64();
+                        sc->t_open[lvl + 1] = (unsigned long long)wall_clock64();
 #endif
-                    __hip_atomic_store(&sc->open_level, lvl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&sc->open_level, lvl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
-            }
-        } else if (kind == SCHED_JOB_A) {
-            trace_tile<true, LCMAX, MULTI>(s, f, L, blk, lvl, tile, n, walk, tc, pc);
+            });
         } else {
-            trace_tile<false, LCMAX, MULTI>(s, f, L, blk, lvl, tile, n, walk, tc, pc);
+            trace_tile<false, MULTI, COUNT>(s, f, L, blk, lvl, tile, n, tc, pc, [] {});
         }
     }
 #ifdef RT_SCHED_TIMELINE
@@ -1876,32 +1877,24 @@ void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int
     else hipLaunchKernelGGL(k_primary<false>, g, b, 0, stream, s, cam, f, pixels);
 }
 
-template <bool MULTI>
-static void launch_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting, dim3 g, dim3 b,
-                         hipStream_t stream)
-{
-    if (s.nl >= 4) {
-        if (reflecting) hipLaunchKernelGGL((k_trace<true, 4, MULTI>), g, b, 0, stream, s, f, level);
-        else hipLaunchKernelGGL((k_trace<false, 4, MULTI>), g, b, 0, stream, s, f, level);
-    } else {
-        if (reflecting) hipLaunchKernelGGL((k_trace<true, 2, MULTI>), g, b, 0, stream, s, f, level);
-        else hipLaunchKernelGGL((k_trace<false, 2, MULTI>), g, b, 0, stream, s, f, level);
-    }
-}
-
 void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting, int grid_blocks,
                hipStream_t stream)
 {
-    if (multi_chunk(s)) launch_trace<true>(s, f, level, reflecting, dim3(grid_blocks), dim3(256), stream);
-    else launch_trace<false>(s, f, level, reflecting, dim3(grid_blocks), dim3(256), stream);
+    const dim3 g(grid_blocks), b(256);
+    if (multi_chunk(s)) {
+        if (reflecting) hipLaunchKernelGGL((k_trace<true, true>), g, b, 0, stream, s, f, level);
+        else hipLaunchKernelGGL((k_trace<false, true>), g, b, 0, stream, s, f, level);
+    } else {
+        if (reflecting) hipLaunchKernelGGL((k_trace<true, false>), g, b, 0, stream, s, f, level);
+        else hipLaunchKernelGGL((k_trace<false, false>), g, b, 0, stream, s, f, level);
+    }
 }
 
 typedef void (*trace_levels_kernel)(DevScene, DevFrame);
 template <bool RESERVE, bool COUNT>
 static trace_levels_kernel trace_levels_pick(const DevScene &s)
 {
-    if (multi_chunk(s)) return s.nl >= 4 ? k_trace_levels<4, true, RESERVE, COUNT> : k_trace_levels<2, true, RESERVE, COUNT>;
-    return s.nl >= 4 ? k_trace_levels<4, false, RESERVE, COUNT> : k_trace_levels<2, false, RESERVE, COUNT>;
+    return multi_chunk(s) ? k_trace_levels<true, RESERVE, COUNT> : k_trace_levels<false, RESERVE, COUNT>;
 }
 static trace_levels_kernel trace_levels_for(const DevScene &s, bool reserve = false, bool count = true)
 {

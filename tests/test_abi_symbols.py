@@ -23,13 +23,13 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert getattr(lib, name) is not None, name
     header = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
-    assert lib.rt_api_version() == int(re.search(r"#define RT_API_VERSION (\d+)", header).group(1)) == 4
+    assert lib.rt_api_version() == int(re.search(r"#define RT_API_VERSION (\d+)", header).group(1)) == 5
 
 
 def test_struct_sizes_match_the_header_layout():
     assert ctypes.sizeof(abi.rt_camera) == 40
     assert ctypes.sizeof(abi.rt_scene) == 8 + 16 * 8
-    assert ctypes.sizeof(abi.rt_stats) == 12 * 8 + 6 * 8 + 8
+    assert ctypes.sizeof(abi.rt_stats) == 13 * 8 + 6 * 8 + 8
 
 
 def test_no_device_is_an_error_not_a_crash():
