@@ -261,8 +261,8 @@ int rt_render_rows_device(rt_ctx *ctx, const rt_camera *camera, int width, int h
  * ray queues live in a fixed array of RT_NOALLOC_SCRATCH_BYTES that the library holds in every
  * GPU's memory from load to process exit, and the call makes no allocation of any kind.  The
  * frame must fit: with P = (row_end - row_begin) * width rounded up to a multiple of 64,
- *     P * (max_depth + 1) * (48 + 4 * ceil(lights / 32)) + 280 KiB  <=  RT_NOALLOC_SCRATCH_BYTES
- * (e.g. 360 x 360 pixels at max_depth 4, or 1024 x 100 at max_depth 5, with up to 32 lights),
+ *     P * (max_depth + 1) * 48 + 280 KiB  <=  RT_NOALLOC_SCRATCH_BYTES
+ * (e.g. 370 x 370 pixels at max_depth 4, or 1024 x 110 at max_depth 5),
  * else RT_ERR_LIMIT and nothing is enqueued; render a taller frame as several calls of fewer
  * rows.  ALL contexts of a process share a GPU's array: calls that overlap on one GPU (two
  * contexts, or two streams not ordered against each other) race on it; calls ordered one after

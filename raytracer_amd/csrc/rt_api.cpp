@@ -40,6 +40,12 @@ std::mutex g_scratch_lock;
 unsigned char *g_scratch_address[RT_SCRATCH_TABLE] = {};
 
 constexpr int RT_CHAIN_RESERVED_TILES_PER_WORKGROUP = 6;
+// Below this many level-0 tiles per workgroup of the level kernel that the whole device holds, a
+// frame is rendered "fused" (enqueue_rows).  Measured on MI355X, 3840x2160 / G, ms per frame with
+// 1 / 2 / 3 frames in flight — G = 8 (4 tiles): levels 0.33 / 0.28 / 0.18, fused 0.34 / 0.20 /
+// 0.15; G = 4 (8 tiles): levels 0.39 / 0.33 / 0.21, fused 0.44 / 0.28 / 0.24; G = 1: levels 0.75,
+// fused 1.12.
+constexpr int RT_FUSED_BELOW_TILES_PER_WORKGROUP = 6;
 
 // Counter slots + level schedule + two record counts per level (DevFrame::counters, sched, cnt).
 constexpr size_t FRAME_CONTROL_USED =
@@ -77,6 +83,10 @@ struct DeviceState {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {};  // begin, after primary, after trace, after shade, after gather copy
+    // Frames rendered as one launch per level and queue: the reflecting records' launches run on a
+    // second stream beside the plain records' (enqueue_rows), ordered by these events.
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_level[RT_MAX_DEPTH + 1] = {};
     int num_cus = 256;
     // k_trace_levels workgroups resident at once, per instance [chain policy][counting] (0: ask
     // again, the scene changed)
@@ -98,7 +108,7 @@ struct DeviceState {
     bool last_fixed = false;   // which of the two the last render call used
     DevFrame &last() { return last_fixed ? fixed : frame; }
     unsigned char *scratch_base = nullptr;   // this device's copy of the fixed scratch array
-    size_t cap_slots = 0, cap_mask = 0;
+    size_t cap_slots = 0;
     int32_t *out = nullptr;  // device framebuffer block of this device
     size_t cap_out = 0;
     int32_t *bands = nullptr;  // this device's bands of an interleaved partition, stacked (rt_render, several devices)
@@ -227,12 +237,11 @@ void free_frame(DeviceState &d)
     if (d.frame.recA) (void)hipFree(d.frame.recA);
     if (d.frame.recB) (void)hipFree(d.frame.recB);
     if (d.frame.refl) (void)hipFree(d.frame.refl);
-    if (d.frame.mask) (void)hipFree(d.frame.mask);
     if (d.frame.counters) (void)hipFree(d.frame.counters);   // counters, sched and cnt are one allocation
     if (d.out) (void)hipFree(d.out);
     d.frame = DevFrame{};
     d.out = nullptr;
-    d.cap_slots = d.cap_mask = d.cap_out = 0;
+    d.cap_slots = d.cap_out = 0;
 }
 
 template <typename T>
@@ -507,7 +516,8 @@ void build_light_tables(PackedScene &out)
     }
     // Origins the tables serve: twice the spheres' extent around their centre, and at least as
     // far out as the lights.
-    const double near = 2.0 * std::max((double)out.sph_l1max, light_l1);
+    static const char *near_env = getenv("RT_HIP_LIGHT_NEAR");   // tuning aid: the factor below
+    const double near = (near_env && atof(near_env) > 0.0 ? atof(near_env) : 2.0) * std::max((double)out.sph_l1max, light_l1);
     const double B = near + (double)out.sph_l1max;
     const double s2 = 28.6 * u24 * B * B, zeta = 8.0 * u24 * B;
     const auto cones = face_cones(n);
@@ -809,29 +819,26 @@ hipError_t scratch_address(int device, unsigned char **out)
     return hipSuccess;
 }
 
-// Bytes of the fixed scratch array a frame of P pixels, max_depth + 1 levels and nl lights needs:
-// the control block, then the three record arrays and the occlusion words, each starting on a
-// multiple of 256 bytes.
-size_t fixed_frame_bytes(size_t slots, int words)
+// Bytes of the fixed scratch array a frame of P pixels and max_depth + 1 levels needs: the control
+// block, then the three record arrays, each starting on a multiple of 256 bytes.
+size_t fixed_frame_bytes(size_t slots)
 {
     const size_t rec = (slots * sizeof(float4) + 255) / 256 * 256;
-    const size_t mask = (slots * (size_t)words * sizeof(uint32_t) + 255) / 256 * 256;
-    return FRAME_CONTROL_BYTES + 3 * rec + mask;
+    return FRAME_CONTROL_BYTES + 3 * rec;
 }
 
 // d.fixed := a frame of P pixels laid out in this device's copy of the fixed scratch array.
 // Allocates nothing; a frame that does not fit is refused.
-int place_fixed_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
+int place_fixed_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth)
 {
     const int levels = max_depth + 1;
     const size_t stride = ((size_t)P + RT_LEVEL_ALIGN - 1) / RT_LEVEL_ALIGN * RT_LEVEL_ALIGN;
     const size_t slots = stride * (size_t)levels;
-    const int words = std::max(1, (nl + 31) / 32);
-    const size_t need = fixed_frame_bytes(slots, words);
+    const size_t need = fixed_frame_bytes(slots);
     if (need > (size_t)RT_NOALLOC_SCRATCH_BYTES)
-        return fail(ctx, RT_ERR_LIMIT, "%d pixels x %d levels x %d lights need %zu bytes of ray queues; the fixed scratch "
+        return fail(ctx, RT_ERR_LIMIT, "%d pixels x %d levels need %zu bytes of ray queues; the fixed scratch "
                     "of rt_render_rows_device_noalloc holds %zu (use rt_render_rows_device, or fewer rows per call)",
-                    P, levels, nl, need, (size_t)RT_NOALLOC_SCRATCH_BYTES);
+                    P, levels, need, (size_t)RT_NOALLOC_SCRATCH_BYTES);
     if (!d.scratch_base) return fail(ctx, RT_ERR_HIP, "device %d: the fixed scratch array has no address", d.device);
     unsigned char *p = d.scratch_base;
     const size_t rec = (slots * sizeof(float4) + 255) / 256 * 256;
@@ -843,24 +850,21 @@ int place_fixed_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
     f.recA = reinterpret_cast<float4 *>(p);
     f.recB = reinterpret_cast<float4 *>(p + rec);
     f.refl = reinterpret_cast<float4 *>(p + 2 * rec);
-    f.mask = reinterpret_cast<uint32_t *>(p + 3 * rec);
     f.P = (int)stride;
     f.slots = (int)slots;
     f.max_depth = max_depth;
-    f.mask_words = words;
     return RT_OK;
 }
 
-int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
+int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth)
 {
     const int levels = max_depth + 1;
     // Level stride: the pixels rounded up so that no cache line of any per-slot array (16-byte
-    // records, 4-byte mask words) holds slots of two levels (see k_trace_levels).
+    // records) holds slots of two levels (see k_trace_levels).
     const size_t stride = ((size_t)P + RT_LEVEL_ALIGN - 1) / RT_LEVEL_ALIGN * RT_LEVEL_ALIGN;
     const size_t slots = stride * (size_t)levels;
     if (slots > (size_t)INT32_MAX)
         return fail(ctx, RT_ERR_LIMIT, "%d pixels x %d levels exceeds 2^31-1 hit-record slots", P, levels);
-    const int words = std::max(1, (nl + 31) / 32);
     if (slots > d.cap_slots) {
         if (d.frame.recA) (void)hipFree(d.frame.recA);
         if (d.frame.recB) (void)hipFree(d.frame.recB);
@@ -871,13 +875,6 @@ int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
         HIP_TRY(ctx, hipMalloc((void **)&d.frame.recB, slots * sizeof(float4)));
         HIP_TRY(ctx, hipMalloc((void **)&d.frame.refl, slots * sizeof(float4)));
         d.cap_slots = slots;
-    }
-    if (slots * words > d.cap_mask) {
-        if (d.frame.mask) (void)hipFree(d.frame.mask);
-        d.frame.mask = nullptr;
-        d.cap_mask = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&d.frame.mask, slots * words * sizeof(uint32_t)));
-        d.cap_mask = slots * words;
     }
     // What every render call zeroes, in one allocation so that it is one fill per frame:
     // the counter slots, the level schedule, the record counts of every possible level.
@@ -891,7 +888,6 @@ int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth, int nl)
     d.frame.P = (int)stride;
     d.frame.slots = (int)slots;
     d.frame.max_depth = max_depth;
-    d.frame.mask_words = words;
     return RT_OK;
 }
 
@@ -976,7 +972,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     HIP_TRY(ctx, hipSetDevice(d.device));
     if (part >= 0 && !d.outcome_snap)
         HIP_TRY(ctx, hipHostMalloc((void **)&d.outcome_snap, RT_MAX_FRAME_PARTS * FRAME_OUTCOME_BYTES, hipHostMallocDefault));
-    int rc = fixed_scratch ? place_fixed_frame(ctx, d, P, max_depth, d.scene.nl) : ensure_frame(ctx, d, P, max_depth, d.scene.nl);
+    int rc = fixed_scratch ? place_fixed_frame(ctx, d, P, max_depth) : ensure_frame(ctx, d, P, max_depth);
     if (rc != RT_OK) return rc;
     d.last_fixed = fixed_scratch;
     DevFrame &fr = d.last();
@@ -1022,7 +1018,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     else HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, FRAME_CONTROL_BYTES, stream));
     d.timed = ctx->profiling != 0;
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
-    const int blocks = std::max(1, std::min({(P + 255) / 256, d.num_cus * 8, RT_COUNTER_SLOTS}));
+    const int blocks = std::max(1, std::min({(P + 255) / 256, d.num_cus * 8 / std::max(1, ctx->share), RT_COUNTER_SLOTS}));
     // k_primary's workgroups claim their 32x32-pixel tiles dynamically: as many workgroups as are
     // resident at once (4 per compute unit) when each gets several tiles, twice that on small frames
     // (measured: 3840x2160 0.161 against 0.170 ms, 1920x1080 0.050 against 0.048 ms).
@@ -1030,23 +1026,47 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     rtk_primary(d.scene, dc, f, dev_pixels,
                 std::min((tiles32 >= 16 * d.num_cus ? d.num_cus * 4 : d.num_cus * 8) / share, RT_COUNTER_SLOTS), stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[1], stream));
-    // RT_HIP_LEVEL_KERNELS=1 (profiling aid): one launch per queue per level on this stream,
-    // so that a kernel trace shows what each level costs on its own.
+    // Two forms of the levels' work.  "levels": one launch per level and queue; the reflecting
+    // records' launches (the chain: level k + 1 exists when level k's are done) go to a second
+    // stream, the plain records' launches (shaded on the spot, no successors, most of the work, in
+    // a kernel of their own that needs few registers and runs at twice the occupancy) stay on the
+    // caller's stream and fill the device beside them.  "fused": every level in ONE launch of
+    // resident workgroups with a device-side schedule (k_trace_levels): no launch gaps between the
+    // levels of a small frame, but plain records then run at the walk kernel's occupancy.
+    // RT_HIP_PIPELINE=levels|fused (tuning aid) overrides; RT_HIP_LEVEL_KERNELS=1 (profiling aid)
+    // is "levels" on ONE stream, so that a kernel trace shows what each launch costs on its own.
+    const char *pipeline_env = getenv("RT_HIP_PIPELINE");   // (read at every call)
     static const bool level_kernels = getenv("RT_HIP_LEVEL_KERNELS") != nullptr;
-    if (level_kernels) {
+    const bool fused = pipeline_env ? strcmp(pipeline_env, "fused") == 0
+                                    : !level_kernels && tiles0 < RT_FUSED_BELOW_TILES_PER_WORKGROUP * resident(false);
+    if (!fused) {
+        // (counting kernels add to per-workgroup counter slots without atomics: one stream then)
+        const bool two_streams = !level_kernels && !counting && max_depth > 0;
+        const int plain_blocks = std::max(1, std::min({tiles0, d.num_cus * 16 / share, RT_COUNTER_SLOTS}));
+        hipStream_t chain = two_streams ? d.aux : stream;
+        if (two_streams) {
+            HIP_TRY(ctx, hipEventRecord(d.ev_fork, stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(d.aux, d.ev_fork, 0));
+        }
         for (int k = 0; k <= max_depth; k++) {
-            rtk_trace(d.scene, f, k, false, blocks, stream);
-            if (k < max_depth) rtk_trace(d.scene, f, k, true, blocks, stream);
+            if (k < max_depth) {
+                rtk_trace(d.scene, f, k, true, dev_pixels, blocks, chain);
+                if (two_streams) HIP_TRY(ctx, hipEventRecord(d.ev_level[k], d.aux));
+            }
+            if (two_streams && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(stream, d.ev_level[k - 1], 0));
+            rtk_trace(d.scene, f, k, false, dev_pixels, plain_blocks, stream);
         }
     } else {
         // Every level in one launch of resident workgroups (k_trace_levels).
-        rtk_trace_levels(d.scene, f, std::max(1, std::min({2 * tiles0, resident_blocks, RT_COUNTER_SLOTS})), stream);
+        rtk_trace_levels(d.scene, f, dev_pixels, std::max(1, std::min({2 * tiles0, resident_blocks, RT_COUNTER_SLOTS})), stream);
     }
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[2], stream));
     // The shading kernels are bandwidth-bound and keep no counters: 32 workgroups per compute unit
     // (measured at 3840x2160: 0.128 ms against 0.145 with 8 and 0.143 with 128).
     const int shade_blocks = std::max(1, std::min((P + 255) / 256, d.num_cus * 32));
-    for (int k = max_depth; k >= 0; k--) rtk_shade_level(d.scene, f, k, dev_pixels, shade_blocks, stream);
+    // (the reflecting records; the deepest level has none)
+    for (int k = max_depth - 1; k >= 0; k--)
+        rtk_shade_level(d.scene, f, k, dev_pixels, std::min(shade_blocks, RT_COUNTER_SLOTS), stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[3], stream));
     if (part >= 0)
         HIP_TRY(ctx, hipMemcpyAsync(d.outcome_snap + (size_t)part * FRAME_OUTCOME_BYTES, f.sched, FRAME_OUTCOME_BYTES,
@@ -1099,6 +1119,9 @@ int rt_create(rt_ctx **out, const int *device_ids, int n_devices)
         }
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipEventCreate(&d.ev[k]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.aux, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming);
+        for (int k = 0; k <= RT_MAX_DEPTH && e == hipSuccess; k++) e = hipEventCreateWithFlags(&d.ev_level[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipHostMalloc((void **)&d.status, 64, hipHostMallocMapped);
         if (e == hipSuccess) memset(d.status, 0, 64);
         if (e == hipSuccess) e = scratch_address(d.device, &d.scratch_base);
@@ -1146,6 +1169,11 @@ void rt_destroy(rt_ctx *ctx)
         free_frame(d);
         for (int k = 0; k < 5; k++)
             if (d.ev[k]) (void)hipEventDestroy(d.ev[k]);
+        if (d.aux) (void)hipStreamSynchronize(d.aux);
+        if (d.ev_fork) (void)hipEventDestroy(d.ev_fork);
+        for (hipEvent_t e : d.ev_level)
+            if (e) (void)hipEventDestroy(e);
+        if (d.aux) (void)hipStreamDestroy(d.aux);
         if (d.stream) (void)hipStreamDestroy(d.stream);
         if (d.outcome_snap) (void)hipHostFree(d.outcome_snap);
         if (d.status) (void)hipHostFree(d.status);

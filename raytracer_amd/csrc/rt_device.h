@@ -155,20 +155,17 @@ struct DevSched {
 //   recB[slot] = {view.xyz, parent}       parent = slot of the level k-1 record, or
 //                                         the pixel index at level 0 (int bits)
 //   refl[slot] = {rgb of the reflected Shade(), valid}   written by the child
-//   mask[w*slots + slot] = bit l%32 of word l/32 set when light l is occluded
 #define RT_LEVEL_ALIGN 64
 struct DevFrame {
     float4 *recA;
     float4 *recB;
     float4 *refl;
-    uint32_t *mask;
     int *cnt;              // cnt[2*k] = A records of level k, cnt[2*k+1] = B records
     DevCounters *counters;
     DevSched *sched;
     int P;                 // level stride: pixels of this render call rounded up to RT_LEVEL_ALIGN
     int slots;             // P * (max_depth + 1)
     int max_depth;
-    int mask_words;        // ceil(nl / 32), at least 1
     int any_hit;           // 1: a light ray may stop at ANY occluder (the Intersect-call counters are not wanted)
     int chain_policy;      // 1: k_trace_levels keeps the tiles the next level waits for to the workgroups that
                            // arrived first on their compute units, and the first of each free for them
@@ -185,13 +182,13 @@ struct DevFrame {
 void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels,
                  int grid_blocks, hipStream_t stream);
 // reflecting: the level's records that need a reflection trace (queue A) or the others (B).
-void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting, int grid_blocks,
+void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting, int32_t *pixels, int grid_blocks,
                hipStream_t stream);
 // Every level in one launch; grid_blocks = workgroups resident at once on the device
 // (rtk_trace_levels_resident_blocks), fewer if the frame has fewer tiles.
 // (of the instance rtk_trace_levels launches for a frame with that chain policy / counting mode)
 int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus, bool reserve, bool count);
-void rtk_trace_levels(const DevScene &s, const DevFrame &f, int grid_blocks, hipStream_t stream);
+void rtk_trace_levels(const DevScene &s, const DevFrame &f, int32_t *pixels, int grid_blocks, hipStream_t stream);
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
                      int grid_blocks, hipStream_t stream);
 // Raytracer.Debug's rays: 16 floats per ray (rt_debug_ray's 14 words, then two of padding).

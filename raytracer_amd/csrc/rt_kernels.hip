@@ -611,7 +611,7 @@ __device__ __forceinline__ void fa_sel(unsigned long long &wlo, unsigned long lo
 // 3 bitmap, 4 SEL loops, 5 exact pass, 6 planes and triangles, 7 results and record push.
 #ifdef RT_PHASE_CLOCKS
 struct PhaseClock {
-    unsigned long long t_last, clk[8];
+    unsigned long long t_last, clk[9];
 };
 #define PHASE_MARK(tcref, p)                                            \
     {                                                                   \
@@ -1029,7 +1029,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
 // trace_level: for each hit record, for specular surfaces below the depth bound,
 // scene.Intersect along the mirror direction (objects.cs:82-83) — a walk of the scene through
 // the filter loops — and IsInShadow towards every light (objects.cs:51-60) through the lights'
-// direction tables (trace_lights below).
+// direction tables (light_occluder below, called while the record is shaded).
 // ---------------------------------------------------------------------------------------
 // Per-lane work counters of a kernel.
 struct TestCount {
@@ -1229,130 +1229,345 @@ __device__ __forceinline__ bool sphere_occludes(const float4 sp, const f3 o, con
     return sphere_maybe(x, a * c) && sphere_root(x, c, a, t) && t > RT_EPS && t < dist;
 }
 
-// The occlusion bits of a record's lights into DevFrame::mask.  COUNT: the reference's
+// Is the ray from `hit` towards light l (direction d, a = d.d, length dist) occluded?  Returns the
+// lowest host index among the occluders found, INT_MAX if none.  COUNT: the reference's
 // Intersect-call counts are kept, which need the FIRST occluder in host order
-// (MyApplication.cs:373-378): every candidate is evaluated.  Otherwise a ray stops at any occluder.
-template <bool COUNT>
-__device__ __forceinline__ void trace_lights(const DevScene &s, const DevFrame &f, const f3 hit, const int slot,
-                                             const bool active, TestCount &tc)
+// (MyApplication.cs:373-378), so every candidate is evaluated; otherwise any occluder will do and
+// the search stops at the first one.  far: the origin lies outside the region the tables serve
+// (any_far: so does some lane's of this wave).  Every lane of the wave must call it.
+// Does a plane occlude a light ray?  Plane.Intersect (objects.cs:157-164) accepts t = numer / denom
+// when t > 0.0001, and IsInShadow then asks for epsilon < t < dist.  The quotient from the
+// hardware reciprocal is within a few ulp of the correctly rounded one, so it settles the answer
+// unless it lies within a relative 1e-6 of one of the two bounds; only then is the exact divide made.
+__device__ __forceinline__ bool plane_occludes(const f3 n, const float numer, const f3 d, const float dist)
 {
-    const int nl = s.nl;
-    const f3 oc = mk3(hit.x - s.sph_center[0], hit.y - s.sph_center[1], hit.z - s.sph_center[2]);
-    // (a NaN origin is "far" and then meets nothing, like in the reference)
-    const bool far = s.lt_n > 0 && !(((fabsf(oc.x) + fabsf(oc.y)) + fabsf(oc.z)) <= s.lt_near);
-    const bool any_far = s.lt_n > 0 && __ballot(far) != 0ull;
-    uint32_t word = 0;
-    for (int l = 0; l < nl; l++) {
-        const f3 lp = xyz(cload(s.light_pos, l));
-        const f3 to_light = sub3(lp, hit);
-        const f3 d = normalized3(to_light);          // objects.cs:51
-        const float dist = length3(to_light);        // objects.cs:52
-        const float a = dot3(d, d);
-        int first = INT_MAX;   // lowest host index among the occluders found
-        for (int j = 0; j < s.np; j++) {
-            const float4 pl = cload(s.pl, j);
-            const f3 n = xyz(pl);
-            float t;
-            if (plane_t(n, (-dot3(n, hit)) - pl.w, d, t) && t > RT_EPS && t < dist) first = min(first, cload(s.pl_orig, j));
-        }
-        for (int j = 0; j < s.nt; j++) {
-            const f3 v0 = xyz(cload(s.tri, 3 * j)), e1 = xyz(cload(s.tri, 3 * j + 1)), e2 = xyz(cload(s.tri, 3 * j + 2));
-            float t;
-            if (triangle_t(e1, e2, sub3(hit, v0), d, t) && t > RT_EPS && t < dist) first = min(first, cload(s.tri_orig, j));
-        }
-        if (s.lt_n > 0) {
-            uint2 cell = light_table_cell(s, l, sub3(hit, lp));
-            int cnt = far || (!COUNT && first != INT_MAX) ? 0 : (int)cell.y;
-            const float4 *list = s.lt_sph + cell.x;
-            float4 nxt = cnt > 0 ? list[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float denom = dot3(n, d);
+    if (fabsf(denom) <= 0.0001f) return false;
+    const float q = numer * __builtin_amdgcn_rcpf(denom);
+    const float lo = RT_EPS, slack = 1e-6f;
+    if (q < lo * (1.0f - slack) || q > dist * (1.0f + slack)) return false;
+    if (q > lo * (1.0f + slack) && q < dist * (1.0f - slack)) return true;
+    const float t = ieee_div(numer, denom);   // (also where q or dist is not finite)
+    return !(t <= 0.0001f) && t > RT_EPS && t < dist;
+}
+
+#ifndef LIGHT_BATCH
+#define LIGHT_BATCH 4
+#endif //   // table entries per lane in flight together
+
+template <bool COUNT>
+__device__ __forceinline__ int light_occluder(const DevScene &s, const int l, const f3 hit, const f3 lp, const f3 d,
+                                              const float a, const float dist, const bool far, const bool any_far,
+                                              const bool active, TestCount &tc)
+{
+    int first = INT_MAX;
+    for (int j = 0; j < s.np; j++) {
+        const float4 pl = cload(s.pl, j);
+        const f3 n = xyz(pl);
+        if (plane_occludes(n, (-dot3(n, hit)) - pl.w, d, dist)) first = min(first, cload(s.pl_orig, j));
+    }
+    for (int j = 0; j < s.nt; j++) {
+        const f3 v0 = xyz(cload(s.tri, 3 * j)), e1 = xyz(cload(s.tri, 3 * j + 1)), e2 = xyz(cload(s.tri, 3 * j + 2));
+        float t;
+        if (triangle_t(e1, e2, sub3(hit, v0), d, t) && t > RT_EPS && t < dist) first = min(first, cload(s.tri_orig, j));
+    }
+    if (s.lt_n > 0) {
+        const uint2 cell = light_table_cell(s, l, sub3(hit, lp));
+        int cnt = !active || far || (!COUNT && first != INT_MAX) ? 0 : (int)cell.y;
+        const float4 *list = s.lt_sph + cell.x;
+        // LIGHT_BATCH entries per step, the next step's loads in flight while this step's entries are
+        // evaluated: a list is walked at the pace of the arithmetic, not of one memory round trip
+        // per entry.
+        const float4 none = make_float4(0.f, 0.f, 0.f, -INFINITY);   // never occludes
+        float4 nxt[LIGHT_BATCH];
+#pragma unroll
+        for (int j = 0; j < LIGHT_BATCH; j++) nxt[j] = j < cnt ? list[j] : none;
 #pragma clang loop unroll(disable)
-            for (int k = 0; __ballot(k < cnt) != 0ull; k++) {
-                const float4 sp = nxt;
-                if (k + 1 < cnt) nxt = list[k + 1];
-                if (k < cnt) {
+        for (int k = 0; __ballot(k < cnt) != 0ull; k += LIGHT_BATCH) {
+            float4 sp[LIGHT_BATCH];
+#pragma unroll
+            for (int j = 0; j < LIGHT_BATCH; j++) {
+                sp[j] = nxt[j];
+                nxt[j] = k + LIGHT_BATCH + j < cnt ? list[k + LIGHT_BATCH + j] : none;
+            }
+#pragma unroll
+            for (int j = 0; j < LIGHT_BATCH; j++) {
+                if (k + j < cnt) {
                     if (COUNT) tc.shadow++;
-                    if (sphere_occludes(sp, hit, d, a, dist)) {
-                        if (COUNT) first = min(first, s.lt_orig[cell.x + k]);
+                    if (sphere_occludes(sp[j], hit, d, a, dist)) {
+                        if (COUNT) first = min(first, s.lt_orig[cell.x + k + j]);
                         else first = 0, cnt = 0;   // any occluder will do
                     }
                 }
             }
-            if (any_far) {   // origins the tables do not serve: every sphere
-                const int todo = far && (COUNT || first == INT_MAX) ? s.ns_padded : 0;
+        }
+        if (any_far) {
+            // Origins the tables do not serve meet every sphere; the wave takes such rays one at a
+            // time, 64 spheres per step (ns_padded is a multiple of 64; padding never occludes).
+            const int lane = threadIdx.x & 63;
+            unsigned long long todo = __ballot(active && far && (COUNT || first == INT_MAX));
 #pragma clang loop unroll(disable)
-                for (int k = 0; __ballot(k < todo) != 0ull; k++) {
-                    if (k < todo) {
-                        if (COUNT) tc.shadow++;
-                        if (sphere_occludes(s.sph[k], hit, d, a, dist)) first = min(first, s.sph_orig[k]);
-                    }
+            while (todo != 0ull) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const f3 ro = mk3(__shfl(hit.x, src), __shfl(hit.y, src), __shfl(hit.z, src));
+                const f3 rd = mk3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+                const float ra = __shfl(a, src), rdist = __shfl(dist, src);
+                int found = INT_MAX;
+#pragma clang loop unroll(disable)
+                for (int base = 0; base < s.ns_padded; base += 64) {
+                    if (sphere_occludes(s.sph[base + lane], ro, rd, ra, rdist)) found = min(found, s.sph_orig[base + lane]);
+                    if (!COUNT && __ballot(found != INT_MAX) != 0ull) break;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) found = min(found, __shfl_xor(found, o, 64));
+                if (lane == src) {
+                    first = min(first, found);
+                    if (COUNT) tc.shadow += s.ns_padded;
                 }
             }
         }
-        const bool occluded = first != INT_MAX;
-        if (occluded) word |= 1u << (l & 31);
-        if (COUNT && active) {
-            // Tests the reference executes for this light: primitives up to and including
-            // the first occluder (MyApplication.cs:373-378), all of them when unoccluded.
-            const int upto = occluded ? first + 1 : s.nprims;
-            tc.sph += cload(s.class_prefix, 3 * upto + 0);
-            tc.pl += cload(s.class_prefix, 3 * upto + 1);
-            tc.tri += cload(s.class_prefix, 3 * upto + 2);
+    }
+    if (COUNT && active) {
+        // Tests the reference executes for this light: primitives up to and including
+        // the first occluder (MyApplication.cs:373-378), all of them when unoccluded.
+        const int upto = first != INT_MAX ? first + 1 : s.nprims;
+        tc.sph += cload(s.class_prefix, 3 * upto + 0);
+        tc.pl += cload(s.class_prefix, 3 * upto + 1);
+        tc.tri += cload(s.class_prefix, 3 * upto + 2);
+    }
+    return first;
+}
+
+// ---------------------------------------------------------------------------------------
+// Shading: Primitive.Shade objects.cs:44-96 for one hit record, light by light as the reference
+// does it: the light ray (IsInShadow, through the light's direction table), the surface colour
+// under that light, the Phong term, the reflected colour its child record left in refl[], the
+// accumulation in the reference's order, the clamp.  The colour goes to the parent record or, at
+// level 0, to the pixel.  The alpha channel is not carried: it never reaches an RGB value or
+// MixColor.
+// ---------------------------------------------------------------------------------------
+// (float)Math.Pow(x, 250) for the Phong term (objects.cs:77-78).  x^250 by repeated
+// squaring in double: 250 = 128+64+32+16+8+2.  Relative error <= ~250 * 2^-53, i.e.
+// the value rounds to the same float as a correctly rounded pow except within
+// ~3e-14 (relative) of a float rounding boundary.
+__device__ __forceinline__ float pow250(float xf)
+{
+    // Below 0.65 the power is below 2e-47, far under half the smallest FP32 denormal (7e-46):
+    // the conversion to float gives +0 whatever the last bits of the double were.
+    if (xf >= 0.0f && xf < 0.65f) return 0.0f;
+    const double x = (double)xf;
+    const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16,
+                 x64 = x32 * x32, x128 = x64 * x64;
+    return (float)(((((x128 * x64) * x32) * x16) * x8) * x2);
+}
+
+// Sign of Math.Sin(a) for a double a: +1, -1, or 0 when the cheap route cannot vouch for it.
+// With t = a / pi, sin(a) is negative exactly when floor(t) is odd.  t is computed in double
+// with an absolute error below 2e-10 for |a| < 2^20; when t is farther than 1e-8 from an
+// integer, floor(t) is the true floor and the sign is certain (any sine routine accurate to an
+// ulp returns that sign, the reference's included).
+__device__ __forceinline__ int sin_sign(const double a)
+{
+    if (!(fabs(a) < 1048576.0)) return 0;
+    const double t = a * 0.31830988618379067154;   // 1 / pi
+    const double fl = floor(t), frac = t - fl;
+    if (!(frac > 1e-8 && frac < 1.0 - 1e-8)) return 0;
+    return ((long long)fl & 1ll) ? -1 : 1;
+}
+
+// Plane.GetCheckerboardColor objects.cs:176-188: 1 = white.  The reference forms
+// (float)(Math.Sin(x * 7.5f) * Math.Sin(y * 7.5f) * Math.Sin(z * 7.5f)) and tests `< 0`.  The
+// product of three sines whose signs are certain and whose arguments are at least 1e-8 * pi away
+// from a zero is in magnitude above 1e-25, so its float is not a zero and its sign is the product
+// of the signs; otherwise the sines themselves are evaluated.
+__device__ __forceinline__ bool checker_white(f3 hit)
+{
+    const float scale = 7.5f;
+    const double ax = (double)(hit.x * scale), ay = (double)(hit.y * scale), az = (double)(hit.z * scale);
+    const int sx = sin_sign(ax), sy = sin_sign(ay), sz = sin_sign(az);
+    if (sx != 0 && sy != 0 && sz != 0) return sx * sy * sz > 0;
+    const float sines = (float)((sin(ax) * sin(ay)) * sin(az));
+    return !(sines < 0.0f);
+}
+
+// Plane.GetTextureCoordinates objects.cs:190-204 + Texture.GetColor :348-353 +
+// LoadTexture :343.  `% 1` is fmodf(x, 1) = x - trunc(x), exact in FP32.  The reference
+// throws for addresses outside the image (NaN / inf coordinates); clamp instead.
+__device__ __forceinline__ f3 texture_color(const DevScene &s, int slot, f3 hit)
+{
+    const float fu = ieee_div(hit.x, 5.0f) - 0.5f, fv = ieee_div(hit.y, 5.0f) - 0.2f;
+    float u = fu - truncf(fu), v = fv - truncf(fv);
+    u = -u;
+    if (u < 0.0f) u += 1.0f;
+    if (v < 0.0f) v += 1.0f;
+    const int w = s.tex_w[slot], h = s.tex_h[slot];
+    int tx = net_f2i(u * (float)(w - 1)), ty = net_f2i(v * (float)(h - 1));
+    tx = min(max(tx, 0), w - 1);
+    ty = min(max(ty, 0), h - 1);
+    const uchar4 p = s.tex[slot][(size_t)ty * (size_t)w + (size_t)tx];
+    return mk3(ieee_div((float)p.x, 255.0f), ieee_div((float)p.y, 255.0f),
+               ieee_div((float)p.z, 255.0f));
+}
+
+__device__ __forceinline__ float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+
+
+// reflecting: the record is in its level's queue A (it traced a reflection ray, and refl[slot]
+// holds the child's colour if that ray hit something).  through: the record was written earlier
+// in this launch by another workgroup (device-scope loads).  Every lane of the wave must call it.
+template <bool COUNT>
+__device__ __forceinline__ void shade_record(const DevScene &s, const DevFrame &f, const int level, const int slot,
+                                             const bool active, const bool reflecting, const bool through,
+                                             int32_t *pixels, TestCount &tc)
+{
+    float4 ra, rb;
+    if (through) load_record(&f.recA[slot], &f.recB[slot], ra, rb);
+    else ra = f.recA[slot], rb = f.recB[slot];
+    const f3 hit = xyz(ra), view = xyz(rb);
+    const int prim = __float_as_int(ra.w), parent = __float_as_int(rb.w);
+    const float4 m0 = cload(s.mat, 3 * prim), m1 = cload(s.mat, 3 * prim + 1), m2 = cload(s.mat, 3 * prim + 2);
+    const int flags = __float_as_int(m1.w);
+    const int type = flags & RT_MF_TYPE_MASK;
+    const f3 normal = record_normal(s, prim, type, hit);
+    const float specular = m0.w;
+    const f3 mat_glossy = xyz(m1), mat_ambient = xyz(m2);
+
+    // Surface colour under the light: material, texture or checkerboard
+    // (objects.cs:62-74); the same for every light, so looked up once.
+    f3 base = xyz(m0);
+    if (type == 1) {
+        const int tex = (flags & RT_MF_TEX_MASK) >> RT_MF_TEX_SHIFT;
+        if (tex != 0) base = texture_color(s, tex - 1, hit);
+        else if (flags & RT_MF_CHECKER) {
+            const float cw = checker_white(hit) ? 1.0f : 0.0f;
+            base = mk3(cw, cw, cw);
         }
-        if ((l & 31) == 31 || l == nl - 1) {
-            if (active) f.mask[(size_t)(l >> 5) * (size_t)f.slots + slot] = word;   // the record's only writer
-            word = 0;
+    }
+    // Reflected colour (objects.cs:80-88): present when this record traced a
+    // reflection ray that hit something.
+    bool have_refl = false;
+    f3 refl_term = mk3(0.0f, 0.0f, 0.0f);
+    if (reflecting) {
+        const float4 rf = f.refl[slot];
+        have_refl = rf.w != 0.0f;
+        // (Vector4)Shade(..) * material.specular * 1
+        refl_term = scale3(scale3(xyz(rf), specular), 1.0f);
+    }
+    // Does the lights' tables' region hold this origin?  (A NaN origin is "far" and then meets
+    // nothing, like in the reference.)
+    const f3 oc = mk3(hit.x - s.sph_center[0], hit.y - s.sph_center[1], hit.z - s.sph_center[2]);
+    const bool far = s.lt_n > 0 && !(((fabsf(oc.x) + fabsf(oc.y)) + fabsf(oc.z)) <= s.lt_near);
+    const bool any_far = s.lt_n > 0 && __ballot(active && far) != 0ull;
+
+    f3 final = mk3(0.0f, 0.0f, 0.0f);
+    const int nl = s.nl;
+    for (int l = 0; l < nl; l++) {
+        const f3 lp = xyz(cload(s.light_pos, l)), lc = xyz(cload(s.light_col, l));
+        const f3 to_light = sub3(lp, hit);
+        const f3 shadow_ray = normalized3(to_light);            // objects.cs:51
+        const float distance = length3(to_light);               // objects.cs:52
+        float diffuse = net_maxf(dot3(normal, shadow_ray), 0.0f);
+        float glossy = 1.0f;
+        // IsInShadow(hitPoint, shadowRay, 0.0001f, distance), objects.cs:56
+        const int occluder = light_occluder<COUNT>(s, l, hit, lp, shadow_ray, dot3(shadow_ray, shadow_ray), distance,
+                                                   far, any_far, active, tc);
+        if (occluder != INT_MAX) {
+            diffuse = 0.0f;
+            glossy = 0.0f;
         }
+        const f3 diffuse_color = scale3(base, diffuse);
+        const f3 reflection = sub3(shadow_ray, scale3(normal, 2.0f * dot3(shadow_ray, normal)));
+        const float sp = pow250(net_maxf(dot3(reflection, view), 0.0f));
+        const f3 glossy_color = scale3(scale3(mat_glossy, sp), glossy);
+        const float d2 = distance * distance;
+        if (have_refl) {
+            final = add3(final, mk3(ieee_div(refl_term.x, d2), ieee_div(refl_term.y, d2),
+                                    ieee_div(refl_term.z, d2)));
+        }
+        // light.color * 1 / (distance*distance) * (diffuseColor + glossyColor) + ambient
+        // (per component; the reference's lights are (2, 2, 2): equal components share the quotient)
+        f3 li;
+        li.x = ieee_div(lc.x * 1.0f, d2);
+        if (lc.y == lc.x && lc.z == lc.x) li.y = li.z = li.x;   // wave-uniform
+        else li.y = ieee_div(lc.y * 1.0f, d2), li.z = ieee_div(lc.z * 1.0f, d2);
+        const f3 dg = add3(diffuse_color, glossy_color);
+        const f3 term = add3(mk3(li.x * dg.x, li.y * dg.y, li.z * dg.z), mat_ambient);
+        final = add3(final, term);
+    }
+    final = mk3(clamp01(final.x), clamp01(final.y), clamp01(final.z));  // objects.cs:94
+    if (!active) return;
+    if (level == 0) {
+        // Primitive.MixColor objects.cs:35-41 -> Surface.pixels (MyApplication.cs:420)
+        const uint32_t r = (uint32_t)net_f2i(final.x * 255.0f);
+        const uint32_t g = (uint32_t)net_f2i(final.y * 255.0f);
+        const uint32_t b = (uint32_t)net_f2i(final.z * 255.0f);
+        pixels[parent] = (int32_t)((r << 16) + (g << 8) + b);
+    } else if (through) {
+        store_record(&f.refl[parent], f4raw{final.x, final.y, final.z, 1.0f});   // (see reflection_tile)
+    } else {
+        f.refl[parent] = make_float4(final.x, final.y, final.z, 1.0f);
     }
 }
 
-// One tile = 256 consecutive records of one queue of one level, one record per lane.  SEC: the
-// records of the level that need a reflection trace (queue "A") or the others ("B").  A records
-// first walk the scene with their reflection ray and push the records of the next level, then
-// after_push() runs (workgroup-uniform; the level schedule counts the tile there, so that the
-// next level opens before this tile's light rays are traced), then the light rays.  n = records in
-// the queue.  Every thread of the workgroup must call it (barriers inside).
-template <bool SEC, bool MULTI, bool COUNT, class AfterPush>
-__device__ __forceinline__ void trace_tile(const DevScene &s, const DevFrame &f, WalkLds &L, int *blk,
-                                           const int level, const int tile, const int n,
-                                           TestCount &tc, PhaseClock &pc, AfterPush &&after_push)
+// One tile = 256 consecutive records of one queue of one level, one record per lane.
+// reflection_tile: records that need a reflection trace (queue "A") walk the scene with their
+// reflection ray and push the records of the next level; they are shaded later, when their
+// children are (k_shade).  n = records in the queue.  Every thread of the workgroup must call it
+// (barriers inside).
+template <bool MULTI>
+__device__ __forceinline__ void reflection_tile(const DevScene &s, const DevFrame &f, WalkLds &L, int *blk,
+                                                const int level, const int tile, const int n,
+                                                TestCount &tc, PhaseClock &pc)
 {
     PHASE_MARK(pc, 0)
     const int i = tile * 256 + threadIdx.x;
     const bool active = i < n;
     const int ii = active ? i : n - 1;
-    const int slot = SEC ? (level * f.P + ii) : ((level + 1) * f.P - 1 - ii);
+    const int slot = level * f.P + ii;
     float4 ra, rb;
     load_record(&f.recA[slot], &f.recB[slot], ra, rb);
-    const f3 hit = xyz(ra);
-    if constexpr (SEC) {
-        const f3 view = xyz(rb);
-        const int prim = __float_as_int(ra.w);
-        const int type = __float_as_int(cload(s.mat, 3 * prim + 1).w) & RT_MF_TYPE_MASK;
-        const f3 normal = record_normal(s, prim, type, hit);
-        Closest sec = {RT_FLT_MAX, INT_MAX};
-        f3 sec_dir = mk3(0.0f, 0.0f, 0.0f);
-        TestCount ltc = {0, 0, 0, 0, 0, 0, 0};
-        trace_reflection<MULTI>(s, L, hit, view, normal, sec, sec_dir, ltc, pc);
-        PHASE_MARK(pc, 6)
-        if (active) {
-            tc.sph += ltc.sph;
-            tc.pl += ltc.pl;
-            tc.tri += ltc.tri;
-            tc.exact += ltc.exact;
-        }
-        tc.filt_terms += ltc.filt_terms;   // inactive lanes run the loops too
-        tc.filt_rays += ltc.filt_rays;
-        const bool child = active && sec.prim != INT_MAX;
-        const f3 hit2 = add3(hit, scale3(sec_dir, sec.t));   // objects.cs:123,166,263
-        if (active) f.refl[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const bool rv[1] = {child};
-        const int rp[1] = {child ? sec.prim : 0}, rparent[1] = {slot};
-        const f3 rh[1] = {hit2}, rd[1] = {sec_dir};
-        push_records<1>(f, s, level + 1, blk, rv, rp, rh, rd, rparent);
-        after_push();
+    const f3 hit = xyz(ra), view = xyz(rb);
+    const int prim = __float_as_int(ra.w);
+    const int type = __float_as_int(cload(s.mat, 3 * prim + 1).w) & RT_MF_TYPE_MASK;
+    const f3 normal = record_normal(s, prim, type, hit);
+    Closest sec = {RT_FLT_MAX, INT_MAX};
+    f3 sec_dir = mk3(0.0f, 0.0f, 0.0f);
+    TestCount ltc = {0, 0, 0, 0, 0, 0, 0};
+    trace_reflection<MULTI>(s, L, hit, view, normal, sec, sec_dir, ltc, pc);
+    PHASE_MARK(pc, 6)
+    if (active) {
+        tc.sph += ltc.sph;
+        tc.pl += ltc.pl;
+        tc.tri += ltc.tri;
+        tc.exact += ltc.exact;
     }
+    tc.filt_terms += ltc.filt_terms;   // inactive lanes run the loops too
+    tc.filt_rays += ltc.filt_rays;
+    const bool child = active && sec.prim != INT_MAX;
+    const f3 hit2 = add3(hit, scale3(sec_dir, sec.t));   // objects.cs:123,166,263
+    // "No reflected colour yet": written through to memory like the records, because the child's
+    // colour may be written later in this same launch from another XCD (plain_tile), and two
+    // caches holding the line dirty would write it back in either order.
+    if (active) store_record(&f.refl[slot], f4raw{0.0f, 0.0f, 0.0f, 0.0f});
+    const bool rv[1] = {child};
+    const int rp[1] = {child ? sec.prim : 0}, rparent[1] = {slot};
+    const f3 rh[1] = {hit2}, rd[1] = {sec_dir};
+    push_records<1>(f, s, level + 1, blk, rv, rp, rh, rd, rparent);
     PHASE_MARK(pc, 7)
-    trace_lights<COUNT>(s, f, hit, slot, active, tc);
+}
+
+// plain_tile: records without a reflection trace (queue "B") depend on nothing further: they are
+// shaded on the spot (light rays included) and their colour goes to the parent record or pixel.
+template <bool COUNT>
+__device__ __forceinline__ void plain_tile(const DevScene &s, const DevFrame &f, const int level, const int tile,
+                                           const int n, int32_t *pixels, TestCount &tc, PhaseClock &pc)
+{
+    PHASE_MARK(pc, 0)
+    const int i = tile * 256 + threadIdx.x;
+    const bool active = i < n;
+    const int ii = active ? i : n - 1;
+    shade_record<COUNT>(s, f, level, (level + 1) * f.P - 1 - ii, active, false, true, pixels, tc);
     PHASE_MARK(pc, 5)
 }
 
@@ -1369,25 +1584,42 @@ __device__ __forceinline__ void flush_test_counts(const DevFrame &f, unsigned lo
     flush_counters(f, cnt_sh, v);
 }
 
-// One queue of one level per launch (the form a kernel trace can attribute time to; the
-// frame pipeline normally uses k_trace_levels below).
-template <bool SEC, bool MULTI>
-__global__ void __launch_bounds__(256) k_trace(DevScene s, DevFrame f, int level)
+// One queue of one level per launch.  k_reflect: the records that need a reflection trace
+// (they walk the staged spheres); k_plain: the others, shaded on the spot — no LDS, and held to
+// RT_PLAIN_WAVES waves per SIMD worth of registers, because the work is a chain of short
+// dependent memory reads (record, table cell, occluder list) that only other waves can hide.
+template <bool MULTI, bool COUNT>
+__global__ void __launch_bounds__(256) k_reflect(DevScene s, DevFrame f, int level)
 {
     __shared__ WalkLds L;
     __shared__ int blk[12];
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
-    const int n = SEC ? f.cnt[2 * level] : f.cnt[2 * level + 1];
+    const int n = f.cnt[2 * level];
     const int ntiles = (n + 255) >> 8;
-    if (SEC && !MULTI && (int)blockIdx.x < ntiles) {
+    if (!MULTI && (int)blockIdx.x < ntiles) {
         stage_chunk<false>(L, s, FilterOrigin{}, 0, s.ns_padded);
         __syncthreads();
     }
     TestCount tc = {0, 0, 0, 0, 0, 0, 0};
     PhaseClock pc = {};
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
-        trace_tile<SEC, MULTI, true>(s, f, L, blk, level, tile, n, tc, pc, [] {});
-    flush_test_counts(f, cnt_sh, tc);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) reflection_tile<MULTI>(s, f, L, blk, level, tile, n, tc, pc);
+    if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
+}
+
+#ifndef RT_PLAIN_WAVES
+#define RT_PLAIN_WAVES 5
+#endif
+template <bool COUNT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_PLAIN_WAVES)))
+k_plain(DevScene s, DevFrame f, int level, int32_t *pixels)
+{
+    __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
+    const int n = f.cnt[2 * level + 1];
+    const int ntiles = (n + 255) >> 8;
+    TestCount tc = {0, 0, 0, 0, 0, 0, 0};
+    PhaseClock pc = {};
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) plain_tile<COUNT>(s, f, level, tile, n, pixels, tc, pc);
+    if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1445,7 +1677,7 @@ struct Taker {
 // the per-lane sums and the per-light prefix lookups they are made of.
 template <bool MULTI, bool RESERVE, bool COUNT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
-k_trace_levels(DevScene s, DevFrame f)
+k_trace_levels(DevScene s, DevFrame f, int32_t *pixels)
 {
     __shared__ WalkLds L;
     __shared__ int blk[12];
@@ -1559,24 +1791,22 @@ k_trace_levels(DevScene s, DevFrame f)
         __syncthreads();   // job[] read by all, spheres staged
         if (kind == SCHED_JOB_A) {
             __builtin_amdgcn_s_setprio(3);   // the chain of levels is the launch's critical path
-            trace_tile<true, MULTI, COUNT>(s, f, L, blk, lvl, tile, n, tc, pc, [&] {
-                // The next level's records are pushed: count the tile before its light rays are traced.
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's record stores have reached memory
-                __builtin_amdgcn_s_setprio(0);
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    const int tiles_a = (n + 255) >> 8;
-                    // (debug_withhold: a test knob that loses one tile's count, so that the next level never opens)
-                    if (!(lvl == f.debug_withhold && tile == 0) && atomicAdd(&sc->done_a[lvl], 1) + 1 == tiles_a) {
+            reflection_tile<MULTI>(s, f, L, blk, lvl, tile, n, tc, pc);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's record stores have reached memory
+            __builtin_amdgcn_s_setprio(0);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int tiles_a = (n + 255) >> 8;
+                // (debug_withhold: a test knob that loses one tile's count, so that the next level never opens)
+                if (!(lvl == f.debug_withhold && tile == 0) && atomicAdd(&sc->done_a[lvl], 1) + 1 == tiles_a) {
 #ifdef RT_SCHED_TIMELINE
-                        sc->t_open[lvl + 1] = (unsigned long long)wall_clock64();
+                    sc->t_open[lvl + 1] = (unsigned long long)wall_clock64();
 #endif
-                        __hip_atomic_store(&sc->open_level, lvl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                    __hip_atomic_store(&sc->open_level, lvl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-            });
+            }
         } else {
-            trace_tile<false, MULTI, COUNT>(s, f, L, blk, lvl, tile, n, tc, pc, [] {});
+            plain_tile<COUNT>(s, f, lvl, tile, n, pixels, tc, pc);
         }
     }
 #ifdef RT_SCHED_TIMELINE
@@ -1591,135 +1821,24 @@ k_trace_levels(DevScene s, DevFrame f)
 }
 
 // ---------------------------------------------------------------------------------------
-// shade_level: Primitive.Shade objects.cs:44-96 for every record of a level, with the
-// occlusion bits from trace_level and the reflected colour its child left in refl[].
-// The alpha channel is not carried: it never reaches an RGB value or MixColor.
+// shade_level: the records of a level that traced a reflection ray (queue "A"), once the level
+// below has been shaded (launches run from the deepest level up); the plain records were shaded
+// by the level kernel.
 // ---------------------------------------------------------------------------------------
-
-// (float)Math.Pow(x, 250) for the Phong term (objects.cs:77-78).  x^250 by repeated
-// squaring in double: 250 = 128+64+32+16+8+2.  Relative error <= ~250 * 2^-53, i.e.
-// the value rounds to the same float as a correctly rounded pow except within
-// ~3e-14 (relative) of a float rounding boundary.
-__device__ __forceinline__ float pow250(float xf)
-{
-    const double x = (double)xf;
-    const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16,
-                 x64 = x32 * x32, x128 = x64 * x64;
-    return (float)(((((x128 * x64) * x32) * x16) * x8) * x2);
-}
-
-// Plane.GetCheckerboardColor objects.cs:176-188: 1 = white.
-__device__ __forceinline__ bool checker_white(f3 hit)
-{
-    const float scale = 7.5f;
-    const float sines = (float)((sin((double)(hit.x * scale)) * sin((double)(hit.y * scale))) *
-                                sin((double)(hit.z * scale)));
-    return !(sines < 0.0f);
-}
-
-// Plane.GetTextureCoordinates objects.cs:190-204 + Texture.GetColor :348-353 +
-// LoadTexture :343.  `% 1` is fmodf(x, 1) = x - trunc(x), exact in FP32.  The reference
-// throws for addresses outside the image (NaN / inf coordinates); clamp instead.
-__device__ __forceinline__ f3 texture_color(const DevScene &s, int slot, f3 hit)
-{
-    const float fu = ieee_div(hit.x, 5.0f) - 0.5f, fv = ieee_div(hit.y, 5.0f) - 0.2f;
-    float u = fu - truncf(fu), v = fv - truncf(fv);
-    u = -u;
-    if (u < 0.0f) u += 1.0f;
-    if (v < 0.0f) v += 1.0f;
-    const int w = s.tex_w[slot], h = s.tex_h[slot];
-    int tx = net_f2i(u * (float)(w - 1)), ty = net_f2i(v * (float)(h - 1));
-    tx = min(max(tx, 0), w - 1);
-    ty = min(max(ty, 0), h - 1);
-    const uchar4 p = s.tex[slot][(size_t)ty * (size_t)w + (size_t)tx];
-    return mk3(ieee_div((float)p.x, 255.0f), ieee_div((float)p.y, 255.0f),
-               ieee_div((float)p.z, 255.0f));
-}
-
-__device__ __forceinline__ float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
-
+template <bool COUNT>
 __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level, int32_t *pixels)
 {
-    const int na = f.cnt[2 * level], nb = f.cnt[2 * level + 1];
-    const int n = na + nb;
+    __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
+    const int na = f.cnt[2 * level];
     const int stride = gridDim.x * blockDim.x;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int slot = i < na ? (level * f.P + i) : ((level + 1) * f.P - 1 - (i - na));
-        const float4 ra = f.recA[slot], rb = f.recB[slot];
-        const f3 hit = xyz(ra), view = xyz(rb);
-        const int prim = __float_as_int(ra.w), parent = __float_as_int(rb.w);
-        const float4 m0 = cload(s.mat, 3 * prim), m1 = cload(s.mat, 3 * prim + 1), m2 = cload(s.mat, 3 * prim + 2);
-        const int flags = __float_as_int(m1.w);
-        const int type = flags & RT_MF_TYPE_MASK;
-        const f3 normal = record_normal(s, prim, type, hit);
-        const float specular = m0.w;
-        const f3 mat_glossy = xyz(m1), mat_ambient = xyz(m2);
-
-        // Surface colour under the light: material, texture or checkerboard
-        // (objects.cs:62-74); the same for every light, so looked up once.
-        f3 base = xyz(m0);
-        if (type == 1) {
-            const int tex = (flags & RT_MF_TEX_MASK) >> RT_MF_TEX_SHIFT;
-            if (tex != 0) base = texture_color(s, tex - 1, hit);
-            else if (flags & RT_MF_CHECKER) {
-                const float cw = checker_white(hit) ? 1.0f : 0.0f;
-                base = mk3(cw, cw, cw);
-            }
-        }
-        // Reflected colour (objects.cs:80-88): present when this record traced a
-        // reflection ray that hit something.
-        bool have_refl = false;
-        f3 refl_term = mk3(0.0f, 0.0f, 0.0f);
-        if (i < na) {
-            const float4 rf = f.refl[slot];
-            have_refl = rf.w != 0.0f;
-            // (Vector4)Shade(..) * material.specular * 1
-            refl_term = scale3(scale3(xyz(rf), specular), 1.0f);
-        }
-
-        f3 final = mk3(0.0f, 0.0f, 0.0f);
-        const int nl = s.nl;
-        uint32_t word = 0;
-        for (int l = 0; l < nl; l++) {
-            if ((l & 31) == 0) word = f.mask[(size_t)(l >> 5) * (size_t)f.slots + slot];
-            const f3 lp = xyz(cload(s.light_pos, l)), lc = xyz(cload(s.light_col, l));
-            const f3 to_light = sub3(lp, hit);
-            const f3 shadow_ray = normalized3(to_light);
-            const float distance = length3(to_light);
-            float diffuse = net_maxf(dot3(normal, shadow_ray), 0.0f);
-            float glossy = 1.0f;
-            if ((word >> (l & 31)) & 1u) {
-                diffuse = 0.0f;
-                glossy = 0.0f;
-            }
-            const f3 diffuse_color = scale3(base, diffuse);
-            const f3 reflection = sub3(shadow_ray, scale3(normal, 2.0f * dot3(shadow_ray, normal)));
-            const float sp = pow250(net_maxf(dot3(reflection, view), 0.0f));
-            const f3 glossy_color = scale3(scale3(mat_glossy, sp), glossy);
-            const float d2 = distance * distance;
-            if (have_refl) {
-                final = add3(final, mk3(ieee_div(refl_term.x, d2), ieee_div(refl_term.y, d2),
-                                        ieee_div(refl_term.z, d2)));
-            }
-            // light.color * 1 / (distance*distance) * (diffuseColor + glossyColor) + ambient
-            const f3 li = mk3(ieee_div(lc.x * 1.0f, d2), ieee_div(lc.y * 1.0f, d2),
-                              ieee_div(lc.z * 1.0f, d2));
-            const f3 dg = add3(diffuse_color, glossy_color);
-            const f3 term = add3(mk3(li.x * dg.x, li.y * dg.y, li.z * dg.z), mat_ambient);
-            final = add3(final, term);
-        }
-        final = mk3(clamp01(final.x), clamp01(final.y), clamp01(final.z));  // objects.cs:94
-
-        if (level == 0) {
-            // Primitive.MixColor objects.cs:35-41 -> Surface.pixels (MyApplication.cs:420)
-            const uint32_t r = (uint32_t)net_f2i(final.x * 255.0f);
-            const uint32_t g = (uint32_t)net_f2i(final.y * 255.0f);
-            const uint32_t b = (uint32_t)net_f2i(final.z * 255.0f);
-            pixels[parent] = (int32_t)((r << 16) + (g << 8) + b);
-        } else {
-            f.refl[parent] = make_float4(final.x, final.y, final.z, 1.0f);
-        }
+    TestCount tc = {0, 0, 0, 0, 0, 0, 0};
+    // (whole waves: the light rays of a record are traced by its wave together)
+    for (int i0 = blockIdx.x * blockDim.x; i0 < na; i0 += stride) {
+        const int i = i0 + threadIdx.x;
+        const bool active = i < na;
+        shade_record<COUNT>(s, f, level, level * f.P + (active ? i : na - 1), active, true, false, pixels, tc);
     }
+    if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1877,20 +1996,24 @@ void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int
     else hipLaunchKernelGGL(k_primary<false>, g, b, 0, stream, s, cam, f, pixels);
 }
 
-void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting, int grid_blocks,
+void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting, int32_t *pixels, int grid_blocks,
                hipStream_t stream)
 {
     const dim3 g(grid_blocks), b(256);
-    if (multi_chunk(s)) {
-        if (reflecting) hipLaunchKernelGGL((k_trace<true, true>), g, b, 0, stream, s, f, level);
-        else hipLaunchKernelGGL((k_trace<false, true>), g, b, 0, stream, s, f, level);
+    const bool count = f.any_hit == 0;
+    if (!reflecting) {
+        if (count) hipLaunchKernelGGL(k_plain<true>, g, b, 0, stream, s, f, level, pixels);
+        else hipLaunchKernelGGL(k_plain<false>, g, b, 0, stream, s, f, level, pixels);
+    } else if (multi_chunk(s)) {
+        if (count) hipLaunchKernelGGL((k_reflect<true, true>), g, b, 0, stream, s, f, level);
+        else hipLaunchKernelGGL((k_reflect<true, false>), g, b, 0, stream, s, f, level);
     } else {
-        if (reflecting) hipLaunchKernelGGL((k_trace<true, false>), g, b, 0, stream, s, f, level);
-        else hipLaunchKernelGGL((k_trace<false, false>), g, b, 0, stream, s, f, level);
+        if (count) hipLaunchKernelGGL((k_reflect<false, true>), g, b, 0, stream, s, f, level);
+        else hipLaunchKernelGGL((k_reflect<false, false>), g, b, 0, stream, s, f, level);
     }
 }
 
-typedef void (*trace_levels_kernel)(DevScene, DevFrame);
+typedef void (*trace_levels_kernel)(DevScene, DevFrame, int32_t *);
 template <bool RESERVE, bool COUNT>
 static trace_levels_kernel trace_levels_pick(const DevScene &s)
 {
@@ -1913,13 +2036,15 @@ int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus, bool reserv
     return per_cu * num_cus;
 }
 
-void rtk_trace_levels(const DevScene &s, const DevFrame &f, int grid_blocks, hipStream_t stream)
+void rtk_trace_levels(const DevScene &s, const DevFrame &f, int32_t *pixels, int grid_blocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(trace_levels_for(s, f.chain_policy != 0, f.any_hit == 0), dim3(grid_blocks), dim3(256), 0, stream, s, f);
+    hipLaunchKernelGGL(trace_levels_for(s, f.chain_policy != 0, f.any_hit == 0), dim3(grid_blocks), dim3(256), 0, stream, s, f,
+                       pixels);
 }
 
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
                      int grid_blocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_shade, dim3(grid_blocks), dim3(256), 0, stream, s, f, level, pixels);
+    if (f.any_hit == 0) hipLaunchKernelGGL(k_shade<true>, dim3(grid_blocks), dim3(256), 0, stream, s, f, level, pixels);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(grid_blocks), dim3(256), 0, stream, s, f, level, pixels);
 }

@@ -23,6 +23,7 @@ def test_stalled_schedule_surfaces_through_every_entry(oracle, monkeypatch):
         c.render_rows_device(cam, w, h, 0, h, depth, buf.data_ptr(), stream.cuda_stream)
         c.frame_status()                       # a healthy frame: nothing to report
         assert np.array_equal(buf.cpu().numpy(), ref)
+        monkeypatch.setenv("RT_HIP_PIPELINE", "fused")   # the form with a device-side schedule
         monkeypatch.setenv("RT_HIP_STALL_MS", "150")
         monkeypatch.setenv("RT_HIP_DEBUG_WITHHOLD_LEVEL", "0")
         c.render_rows_device(cam, w, h, 0, h, depth, buf.data_ptr(), stream.cuda_stream)
