@@ -105,7 +105,8 @@ def test_texels_of_the_reference_wall_texture(oracle):
     wall = next(i for i, p in enumerate(s.primitives) if isinstance(p, Plane) and p.texture == 0)
     ref64 = Restatement(s, Camera(), scalar=np.float64, textures=[tex])
     tex[1078, 1918, :3] = texels[(1919, 1079)]
-    hits = {(0, 0): (7.4999, 1.0001), (959, 539): (5.0, 3.5), (1918, 1078): (2.50005, 5.99995)}
+    # (hit points on the z = -2 wall inside the box, so that both lights reach them)
+    hits = {(0, 0): (2.4999, -3.9999), (959, 539): (0.0, -1.5), (1918, 1078): (-2.49995, 0.99995)}
     for (tx, ty), (x, y) in hits.items():
         hit = (x, y, -2.0)
         assert oracle.texel(hit, 1920, 1080) == (tx, ty)
@@ -114,9 +115,9 @@ def test_texels_of_the_reference_wall_texture(oracle):
         want = ref64.shade(s.primitives[wall], ref64.A.vec(hit), ref64.A.vec(view), 0)
         assert np.allclose(got[:3], [float(c) for c in want[:3]], atol=2e-6), ((tx, ty), got, want)
     # and the colour really is the texel's: a lit point shows its ratios
-    hit = (5.0, 3.5, -2.0)
+    hit = (0.0, -1.5, -2.0)
     got = oracle.shade(fs, wall, hit, (0.0, 0.0, -1.0), textures=[tex])
-    base = oracle.shade(fs, wall, (5.0, 3.6, -2.0), (0.0, 0.0, -1.0), textures=[tex])   # a black texel next to it
+    base = oracle.shade(fs, wall, (0.0, -1.4, -2.0), (0.0, 0.0, -1.0), textures=[tex])   # a black texel next to it
     d = got[:3] - base[:3]
     assert d[1] > 1e-3   # the point is lit
     assert abs(d[0] / d[1] - 81 / 127) < 1e-3 and abs(d[2] / d[1] - 1.0) < 1e-3
