@@ -269,6 +269,7 @@ struct PackedScene {
     std::vector<uint2> lt_cells;
     std::vector<float4> lt_sph;
     std::vector<int> lt_orig;
+    std::vector<float> lt_reach;
     int lt_n = 0;
     float lt_near = 0.f;
 };
@@ -503,6 +504,7 @@ void build_light_tables(PackedScene &out)
     out.lt_cells.clear();
     out.lt_sph.clear();
     out.lt_orig.clear();
+    out.lt_reach.clear();
     out.lt_n = 0;
     out.lt_near = 0.f;
     if (ns == 0 || nl == 0) return;
@@ -518,8 +520,11 @@ void build_light_tables(PackedScene &out)
     // far out as the lights.
     static const char *near_env = getenv("RT_HIP_LIGHT_NEAR");   // tuning aid: the factor below
     const double near = (near_env && atof(near_env) > 0.0 ? atof(near_env) : 2.0) * std::max((double)out.sph_l1max, light_l1);
-    const double B = near + (double)out.sph_l1max;
-    const double s2 = 28.6 * u24 * B * B, zeta = 8.0 * u24 * B;
+    // (B >= |o - p_i| per sphere: the origin's bound plus the sphere's own distance from the centre)
+    auto widened = [&](const float4 &sp) {
+        const double B = near + std::fabs(sp.x - cen[0]) + std::fabs(sp.y - cen[1]) + std::fabs(sp.z - cen[2]);
+        return (std::sqrt((double)sp.w + 28.6 * u24 * B * B) + 8.0 * u24 * B) * (1.0 + 1e-9);
+    };
     const auto cones = face_cones(n);
     const int leaf_level = (int)cones.size() - 1;
     const size_t cells_per_light = (size_t)6 * n * n;
@@ -527,6 +532,7 @@ void build_light_tables(PackedScene &out)
 
     struct PerLight {
         std::vector<uint32_t> cell, sphere;   // (bin, sphere) pairs in the order found
+        std::vector<float> reach;             // per sphere: lower bound of the distance light -> widened sphere
         bool failed = false;
     };
     std::vector<PerLight> per(nl);
@@ -538,10 +544,23 @@ void build_light_tables(PackedScene &out)
             const double Dmax = near + std::fabs(L[0] - cen[0]) + std::fabs(L[1] - cen[1]) + std::fabs(L[2] - cen[2]);
             const double m = 4e-3 * Dmax, dl = 4e-7 * Dmax;
             std::vector<uint32_t> stack;
+            // Spheres in the order of how close they come to the light, so that every bin's list
+            // comes out sorted that way (the kernel stops a list at the ray's own length).
+            pl.reach.assign(ns, 0.f);
+            std::vector<uint32_t> by_reach;
             for (size_t i = 0; i < ns; i++) {
                 const float4 &sp = out.sph[i];
                 if (!usable_sphere(sp)) continue;
-                const double R = (std::sqrt((double)sp.w + s2) + zeta) * (1.0 + 1e-9);
+                const double dx = sp.x - L[0], dy = sp.y - L[1], dz = sp.z - L[2];
+                const double reach = std::sqrt(dx * dx + dy * dy + dz * dz) - widened(sp) - dl;
+                // rounded down; a ray of length `distance` can only meet spheres with reach <= distance
+                pl.reach[i] = std::isfinite(reach) ? std::nextafter((float)(reach - 1e-6 * std::fabs(reach)), -INFINITY) : -INFINITY;
+                by_reach.push_back((uint32_t)i);
+            }
+            std::stable_sort(by_reach.begin(), by_reach.end(), [&](uint32_t a, uint32_t b) { return pl.reach[a] < pl.reach[b]; });
+            for (const uint32_t i : by_reach) {
+                const float4 &sp = out.sph[i];
+                const double R = widened(sp);
                 const double dx = sp.x - L[0], dy = sp.y - L[1], dz = sp.z - L[2];
                 const double dist = std::sqrt(dx * dx + dy * dy + dz * dz);
                 double cosa = 1.0, sina = 0.0;
@@ -605,6 +624,7 @@ void build_light_tables(PackedScene &out)
     if (total >= (size_t)1 << 31) throw std::length_error("the per-light occluder lists exceed 2^31 entries");
     out.lt_sph.resize(total);
     out.lt_orig.resize(total);
+    out.lt_reach.resize(total);
     size_t base = 0;
     for (size_t l = 0; l < nl; l++) {
         const PerLight &pl = per[l];
@@ -620,6 +640,7 @@ void build_light_tables(PackedScene &out)
             uint2 &c = cells[pl.cell[k]];
             out.lt_sph[(size_t)c.x + c.y] = out.sph[pl.sphere[k]];
             out.lt_orig[(size_t)c.x + c.y] = out.sph_orig[pl.sphere[k]];
+            out.lt_reach[(size_t)c.x + c.y] = pl.reach[pl.sphere[k]];
             c.y++;
         }
         base = off;
@@ -738,6 +759,7 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     if ((rc = upload(ctx, d, ps.lt_cells, &sc.lt_cells)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.lt_sph, &sc.lt_sph)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.lt_orig, &sc.lt_orig)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.lt_reach, &sc.lt_reach)) != RT_OK) return rc;
     sc.lt_n = ps.lt_n;
     sc.lt_near = ps.lt_near;
     sc.nsup_padded = (int)ps.sup_f.size();

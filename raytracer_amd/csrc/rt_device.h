@@ -83,6 +83,8 @@ struct DevScene {
     const uint2 *lt_cells;
     const float4 *lt_sph;
     const int *lt_orig;
+    const float *lt_reach;    // per entry: a lower bound of the distance from the light to any point of the
+                              // (widened) sphere; a cell's entries are sorted by it
     int lt_n;
     float lt_near;
     const uchar4 *tex[RT_DEV_MAX_TEXTURES];

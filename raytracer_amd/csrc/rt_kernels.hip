@@ -805,13 +805,35 @@ __device__ __forceinline__ void walk_chunk(WalkLds &L, const int cnt, const floa
     }
 }
 
+// Can a ray from the origin whose filter operands are fo still find, inside the ball {P', W}
+// (DevScene::chk_f form: W = R*R - k1*|P'|^2), a hit at t <= best_t?  Every point of the ball is at
+// least |o - P| - R from the origin, the ray's direction has unit length to within 6 ulp, and the
+// t the reference computes for a sphere it accepts is off the geometric one by far less than the
+// slack the ball tests already allow (FILTER_BALL_SLACK times the coordinates' magnitude).
+// Anything not finite answers yes.
+__device__ __forceinline__ bool ball_within_reach(const DevScene &s, const FilterOrigin &fo, const float4 ball,
+                                                  const float best_t)
+{
+    const float dx = fo.oc.x - ball.x, dy = fo.oc.y - ball.y, dz = fo.oc.z - ball.z;
+    const float dist = sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+    const float pp = __builtin_fmaf(ball.z, ball.z, __builtin_fmaf(ball.y, ball.y, ball.x * ball.x));
+    const float radius = sqrtf(fmaxf(ball.w + pp, 0.0f)) * 1.00001f;
+    const float slack = FILTER_BALL_SLACK * (((fabsf(fo.oc.x) + fabsf(fo.oc.y)) + fabsf(fo.oc.z)) + s.sph_l1max);
+    const float t_low = (dist - radius) * 0.9999f - slack;
+    return !(best_t < t_low);
+}
+
 // The chunks of a scene with more than one: `visit(base, cnt)` is called, by the whole
 // workgroup, for every chunk whose ball some ray of some wave may hit (the chunks' balls are
 // tested GRP_CHUNK at a time with a GROUP loop, and the waves' pass bits are ORed in LDS because
 // staging a chunk is the workgroup's business).  Every thread of the workgroup must call it.
-template <int K, bool TRACE, bool SPLIT, class Visit>
+// need(ball) (per lane; ball = the chunk's {P', W} as in DevScene::chk_f): can this lane still gain
+// from the chunk?  A chunk nobody needs any more (every ray of the workgroup has a hit closer than
+// the chunk's ball) is neither staged nor walked.
+template <int K, bool TRACE, bool SPLIT, class Need, class Visit>
 __device__ __forceinline__ void for_each_chunk(WalkLds &L, const DevScene &s, const f4raw (&rq)[4], const f4raw lane_c,
-                                               const f3 oc, FilterWork &fw, const unsigned (&live)[4], Visit &&visit)
+                                               const f3 oc, FilterWork &fw, const unsigned (&live)[4], Need &&need,
+                                               Visit &&visit)
 {
     constexpr bool split = SPLIT && K > 1;
     constexpr int NB = split ? K : 1;
@@ -873,7 +895,9 @@ __device__ __forceinline__ void for_each_chunk(WalkLds &L, const DevScene &s, co
         // array, which never pass, lie there, so `count` is the number of ranks handed out.)
 #pragma clang loop unroll(disable)
         for (int i = 0; i < count; i++) {
-            const int base = (first + __builtin_amdgcn_readfirstlane(L.order[i])) * SPH_CHUNK;   // workgroup-uniform
+            const int chunk = first + __builtin_amdgcn_readfirstlane(L.order[i]);   // workgroup-uniform
+            const int base = chunk * SPH_CHUNK;
+            if (!__syncthreads_or(need(cload(s.chk_f, chunk)) ? 1 : 0)) continue;
             visit(base, min(SPH_CHUNK, nsp - base));
         }
     }
@@ -975,6 +999,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
                                                   exact, all_live);
         } else {
             for_each_chunk<PRIM_PX, false, false>(L, s, rq, fo.lane_c, fo.oc, fw, all_live,
+                                                  [&](const float4 ball) {
+                const float far_t = fmaxf(fmaxf(best_t[0], best_t[1]), fmaxf(best_t[2], best_t[3]));
+                return ball_within_reach(s, fo, ball, far_t);
+            },
                                                   [&](const int base, const int cnt) {
                 __syncthreads();
                 stage_chunk<true>(L, s, fo, base, cnt);
@@ -1103,7 +1131,9 @@ __device__ __forceinline__ void traverse(const DevScene &s, WalkLds &L,
         if (nsp > 0)
             walk_chunk<NR, true, SPLIT>(L, nsp, s.sph, s.sph_orig, rq, fo.lane_s, fo.lane_g, fo.lane, fw, pc, exact, live);
     } else {
-        for_each_chunk<NR, true, SPLIT>(L, s, rq, fo.lane_c, fo.oc, fw, live, [&](const int base, const int cnt) {
+        for_each_chunk<NR, true, SPLIT>(L, s, rq, fo.lane_c, fo.oc, fw, live,
+                                        [&](const float4 ball) { return !SEC || LC > 0 || ball_within_reach(s, fo, ball, best_t); },
+                                        [&](const int base, const int cnt) {
             __syncthreads();
             stage_chunk<false>(L, s, fo, base, cnt);
             __syncthreads();
@@ -1278,25 +1308,39 @@ __device__ __forceinline__ int light_occluder(const DevScene &s, const int l, co
         // LIGHT_BATCH entries per step, the next step's loads in flight while this step's entries are
         // evaluated: a list is walked at the pace of the arithmetic, not of one memory round trip
         // per entry.
+        // A list is sorted by how close its spheres come to the light (lt_reach): the first one that
+        // stays farther from the light than the ray's own origin ends the walk.
         const float4 none = make_float4(0.f, 0.f, 0.f, -INFINITY);   // never occludes
+        const float *reach = s.lt_reach + cell.x;
         float4 nxt[LIGHT_BATCH];
+        float nxt_reach[LIGHT_BATCH];
 #pragma unroll
-        for (int j = 0; j < LIGHT_BATCH; j++) nxt[j] = j < cnt ? list[j] : none;
+        for (int j = 0; j < LIGHT_BATCH; j++) {
+            nxt[j] = j < cnt ? list[j] : none;
+            nxt_reach[j] = j < cnt ? reach[j] : 0.0f;
+        }
 #pragma clang loop unroll(disable)
         for (int k = 0; __ballot(k < cnt) != 0ull; k += LIGHT_BATCH) {
             float4 sp[LIGHT_BATCH];
+            float sp_reach[LIGHT_BATCH];
 #pragma unroll
             for (int j = 0; j < LIGHT_BATCH; j++) {
                 sp[j] = nxt[j];
+                sp_reach[j] = nxt_reach[j];
                 nxt[j] = k + LIGHT_BATCH + j < cnt ? list[k + LIGHT_BATCH + j] : none;
+                nxt_reach[j] = k + LIGHT_BATCH + j < cnt ? reach[k + LIGHT_BATCH + j] : 0.0f;
             }
 #pragma unroll
             for (int j = 0; j < LIGHT_BATCH; j++) {
                 if (k + j < cnt) {
-                    if (COUNT) tc.shadow++;
-                    if (sphere_occludes(sp[j], hit, d, a, dist)) {
-                        if (COUNT) first = min(first, s.lt_orig[cell.x + k + j]);
-                        else first = 0, cnt = 0;   // any occluder will do
+                    if (sp_reach[j] > dist) {
+                        cnt = 0;   // this sphere and all after it lie beyond the ray's origin
+                    } else {
+                        if (COUNT) tc.shadow++;
+                        if (sphere_occludes(sp[j], hit, d, a, dist)) {
+                            if (COUNT) first = min(first, s.lt_orig[cell.x + k + j]);
+                            else first = 0, cnt = 0;   // any occluder will do
+                        }
                     }
                 }
             }

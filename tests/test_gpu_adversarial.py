@@ -63,7 +63,7 @@ def test_scaled_and_translated_scenes(ctx, oracle, scale, offset):
     s = moved(base, scale, offset)
     cam = Camera(position=tuple(scale * c + o for c, o in zip((0.2, -0.3, 0.1), offset)), direction=(0.0, 0.0, 1.0))
     gpu = exact(ctx, oracle, s, cam, 120, 80, 3, f"scale {scale} offset {offset}")
-    assert len(np.unique(gpu)) > 50   # a real picture, not a constant
+    assert len(np.unique(gpu)) > 20   # a real picture, not a constant
 
 
 def test_rays_tangent_to_spheres(ctx, oracle):
