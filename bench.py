@@ -14,11 +14,15 @@ Printed by rank 0: one JSON line with
   value        whole-job Mrays/s = (primary + shadow + used reflection rays per frame,
                de-duplicated as include/rt_hip.h defines them) / seconds per frame; the timed
                step ends with the frame in rank 0's DEVICE memory
-  roofline     the ray-traversal kernel (k_trace_levels, every level in one launch): the FLOP it
-               EXECUTED per launch (filter evaluations of rays against spheres and bounding
-               balls, per-origin terms, exact Intersect of the candidates, plane and triangle
-               tests; from the library's work counters) / its HIP-event time, against the
-               157.3 TFLOP/s vector-FP32 peak.  `algorithmic_tflops` prices the same launch at
+  roofline     the levels stage, i.e. everything between the primary-ray kernel and the final
+               shading passes: one k_reflect launch per level (the reflection rays' closest-hit
+               walks, on a second stream) beside one k_plain launch per level (light rays and
+               shading of the records that reflect nothing), or on small frames one
+               k_trace_levels launch that does both.  The FLOP the stage EXECUTED per frame
+               (filter evaluations of rays against spheres and bounding balls, per-origin terms,
+               exact Intersect of the candidates and of the spheres the lights' direction tables
+               list, plane and triangle tests; from the library's work counters) / its HIP-event
+               time, against the 157.3 TFLOP/s vector-FP32 peak.  `algorithmic_tflops` prices the same launch at
                the Intersect calls the reference's brute-force algorithm makes (25 FLOP per
                ray-sphere test ...); the kernel culls most of them, so that figure is a
                speed-up over brute force (`algorithmic_speedup`), not a hardware rate.
@@ -89,7 +93,7 @@ def cpu_baseline(cfg, flat, cam) -> dict:
 
 
 def pmc_summary(name: str) -> dict:
-    """Per-launch counters of the traversal kernel on this workload from the committed rocprofv3
+    """Per-frame counters of the levels stage on this workload from the committed rocprofv3
     PMC passes (they cannot be collected from inside this process); {} when missing."""
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -249,11 +253,13 @@ def main() -> None:
         # and the exact Intersect of the candidates (25 FLOP to the discriminant + 11 to the hit).
         # Light rays: the exact Intersect of every sphere their light's direction table lists
         # (25 FLOP to the discriminant; few go on).  Plane / triangle tests as the reference makes them.
+        # The records that reflect nothing are shaded inside the stage (80 FLOP per record and light).
         tr_filter_rays = tot["filter_ray_tests"] - tot["primary_filter_ray_tests"]
         tr_candidates = tot["exact_candidates"] - tot["primary_exact_candidates"]
         executed_flop = (8.0 * tr_filter_rays + 7.0 * tot["filter_origin_terms"] +
                          (FLOP_SPHERE + 11.0) * tr_candidates + FLOP_SPHERE * tot["shadow_candidates"] +
-                         FLOP_PLANE * tr_p + FLOP_TRIANGLE * tr_t)
+                         FLOP_PLANE * tr_p + FLOP_TRIANGLE * tr_t +
+                         FLOP_LIGHT_SHADE * flat.num_lights * (tot["shaded_hits"] - tot["rays_secondary"]))
         trace_s = trace_ms * 1e-3
         # Per-GPU rate of the dominant kernel: each rank traced 1/world of the FLOP.
         executed = executed_flop / world / trace_s / 1e12 if trace_s > 0 else 0.0
@@ -287,7 +293,8 @@ def main() -> None:
                 "timed_step_ends": "frame in device memory of rank 0 (see handoff for the host copy)",
             },
             "roofline": {
-                "bound": "valu-fp32", "kernel": "k_trace_levels (every level of the frame in one launch)",
+                "bound": "valu-fp32", "kernel": "levels stage of a frame: k_reflect per level (reflection rays) on a second stream beside "
+                                                 "k_plain per level (light rays + shading of plain records); 'launch' = one frame's stage",
                 "achieved": round(executed, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(executed / PEAK_FP32_TFLOPS, 4),
                 "executed_flop_per_launch": executed_flop / world,

@@ -530,6 +530,9 @@ int orc_render(const rt_scene *s, const orc_texture *tex, int ntex, const rt_cam
 
 /* ------------------------------------------------------------------------------------------
  * FXAA, screen_fxaa_fs.glsl:80-140 (see rt_oracle.h).
+ * The routine restated here is Copyright (c) 2011 by Armin Ronacher (webgl-meincraft), some rights
+ * reserved, three-clause BSD licence; notice, conditions and disclaimer: THIRD_PARTY_NOTICES.md at
+ * the root of this repository.
  * ---------------------------------------------------------------------------------------- */
 typedef struct { float r, g, b; } fx_rgb;
 

@@ -260,7 +260,7 @@ int upload(rt_ctx *ctx, DeviceState &d, const std::vector<T> &host, const T **de
 }
 
 struct PackedScene {
-    std::vector<float4> sph, sph_f, grp_f, sup_f, chk_f, pl, tri, geo, mat, light_pos, light_col;
+    std::vector<float4> sph, sph_f, grp_f, sup_f, chk_f, sup_b, chk_b, pl, tri, geo, mat, light_pos, light_col;
     std::vector<int> sph_orig, pl_orig, tri_orig, class_prefix;
     uint32_t textures_used = 0;
     float sph_center[3] = {0.f, 0.f, 0.f};
@@ -423,6 +423,54 @@ void build_filter_arrays(PackedScene &out)
     out.grp_rmax = (float)(grmax * up);
     out.sup_rmax = (float)(surmax * up);
     out.chk_rmax = (float)(chrmax * up);
+}
+
+// The bounding balls the primary rays' cone test reads (rt_kernels.hip, "Cone culling"): one per
+// aligned run of `run` spheres as {Px, Py, Pz, R} in the scene's own coordinates.  Members are
+// the spheres the reference can hit at all (finite data); the centre is found as above and
+// rounded to FP32, the radius is measured against the rounded centre and rounded up.  R = -1: no
+// members (nothing to hit); R = +inf: not representable (always passes).
+void build_plain_balls(const PackedScene &out, size_t run, size_t pad, std::vector<float4> &dst)
+{
+    const size_t n = out.sph.size(), nb = (n + run - 1) / run;
+    dst.assign((nb + pad - 1) / pad * pad, make_float4(0.f, 0.f, 0.f, -1.f));
+    for (size_t g = 0; g < nb; g++) {
+        const size_t i0 = g * run, i1 = std::min(n, (g + 1) * run);
+        double blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        bool any = false;
+        for (size_t i = i0; i < i1; i++) {
+            const float4 &s = out.sph[i];
+            if (!usable_sphere(s)) continue;
+            const double c[3] = {s.x, s.y, s.z}, r = std::sqrt((double)s.w);
+            for (int k = 0; k < 3; k++) blo[k] = std::min(blo[k], c[k] - r), bhi[k] = std::max(bhi[k], c[k] + r);
+            any = true;
+        }
+        if (!any) continue;
+        double bc[3];
+        for (int k = 0; k < 3; k++) bc[k] = 0.5 * (blo[k] + bhi[k]);
+        for (int it = 0; it < 64; it++) {
+            double far = -1.0, fc[3] = {bc[0], bc[1], bc[2]};
+            for (size_t i = i0; i < i1; i++) {
+                const float4 &s = out.sph[i];
+                if (!usable_sphere(s)) continue;
+                const double dx = s.x - bc[0], dy = s.y - bc[1], dz = s.z - bc[2];
+                const double dist = std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)s.w);
+                if (dist > far) far = dist, fc[0] = s.x, fc[1] = s.y, fc[2] = s.z;
+            }
+            for (int k = 0; k < 3; k++) bc[k] += (fc[k] - bc[k]) / (double)(it + 2);
+        }
+        const float P[3] = {(float)bc[0], (float)bc[1], (float)bc[2]};
+        double rad = 0.0;
+        for (size_t i = i0; i < i1; i++) {
+            const float4 &s = out.sph[i];
+            if (!usable_sphere(s)) continue;
+            const double dx = s.x - (double)P[0], dy = s.y - (double)P[1], dz = s.z - (double)P[2];
+            rad = std::max(rad, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)s.w));
+        }
+        const float R = std::nextafter((float)(rad * (1.0 + 1e-6)), INFINITY);
+        const bool ok = std::isfinite(P[0]) && std::isfinite(P[1]) && std::isfinite(P[2]) && std::isfinite(R);
+        dst[g] = ok ? make_float4(P[0], P[1], P[2], R) : make_float4(0.f, 0.f, 0.f, INFINITY);
+    }
 }
 
 
@@ -713,6 +761,8 @@ int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
     }
     reorder_spheres(out);
     build_filter_arrays(out);
+    build_plain_balls(out, RT_SUPER, 8, out.sup_b);
+    build_plain_balls(out, RT_CHUNK, 8, out.chk_b);
     out.class_prefix[3 * (size_t)n + 0] = cs;
     out.class_prefix[3 * (size_t)n + 1] = cp;
     out.class_prefix[3 * (size_t)n + 2] = ct;
@@ -746,6 +796,8 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     if ((rc = upload(ctx, d, ps.grp_f, &sc.grp_f)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.sup_f, &sc.sup_f)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.chk_f, &sc.chk_f)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.sup_b, &sc.sup_b)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.chk_b, &sc.chk_b)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.sph_orig, &sc.sph_orig)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.pl, &sc.pl)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.pl_orig, &sc.pl_orig)) != RT_OK) return rc;

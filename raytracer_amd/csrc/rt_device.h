@@ -13,8 +13,8 @@
 //   grp_f    float4 {P'x, P'y, P'z, W}       one bounding ball per group, same form
 //   sup_f, chk_f                             one bounding ball per RT_SUPER (64) spheres and per
 //                                            RT_CHUNK (1024) spheres: two coarser levels, same form
-// (The primary kernel turns the four filter arrays into {p', -c''} for the camera origin while
-// it stages them.)
+//   sup_b, chk_b                             the balls around the same runs and chunks as {P, R} in the
+//                                            scene's own coordinates (the primary rays' cone test)
 //   pl       float4 {nx, ny, nz, d}          one per plane
 //   tri      float4 x3 {v0}, {e1}, {e2}      e1 = v1-v0, e2 = v2-v0 (objects.cs:238-239)
 //   geo      float4 per host primitive: sphere centre or plane/triangle normal
@@ -63,6 +63,10 @@ struct DevScene {
     const float4 *grp_f;      // ns_padded / RT_GROUP bounding balls
     const float4 *sup_f;      // nsup_padded balls (padding: never-pass entries)
     const float4 *chk_f;      // nchk_padded balls
+    // Balls around the same runs as {Px, Py, Pz, R} in the scene's own coordinates (R rounded up;
+    // -1 = no members, +inf = not representable): what the primary rays' cone test reads.
+    const float4 *sup_b;
+    const float4 *chk_b;
     const int *sph_orig;
     const float4 *pl;
     const int *pl_orig;

@@ -383,18 +383,6 @@ __device__ __forceinline__ f4raw filter_ray(const FilterOrigin &fo, f3 d)
 }
 
 // ---------------------------------------------------------------------------------------
-// Camera terms: every primary ray starts at camera.position, so the filter's per-entry term
-// -c'' for that origin depends on the entry alone.  The primary kernel forms it while it stages
-// an entry in LDS ({p', W} -> {p', -c''}; 3 FMA and a subtraction per entry and workgroup, far
-// cheaper than a launch of its own per frame) and its loops then take -c'' as given.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 camera_term(const float4 pf, const f4raw lane)
-{
-    const float chain = __builtin_fmaf(lane.x, pf.x, __builtin_fmaf(lane.y, pf.y, __builtin_fmaf(lane.z, pf.z, pf.w)));
-    return make_float4(pf.x, pf.y, pf.z, chain - lane.w);   // padding: -inf, never passes
-}
-
-// ---------------------------------------------------------------------------------------
 // The filter loops themselves are gfx950 assembly with a fixed, VGPR-bank-conflict-free
 // register plan (filter_asm.inc, generated by tools/gen_filter_asm.py): hipcc's register
 // allocation ignores banks, and a three-source instruction with two sources in one bank
@@ -403,8 +391,7 @@ __device__ __forceinline__ float4 camera_term(const float4 pf, const f4raw lane)
 // may hit (lanes queue one word per trip with a candidate), and then evaluates each lane's
 // (short) queue exactly here in C++.
 
-// Staged per workgroup (WalkLds): a chunk of SPH_CHUNK filter entries {p', W} (or, for the
-// primary kernel, {p', -c''}), the bounding balls of its groups and of its runs of RT_SUPER
+// Staged per workgroup (WalkLds): a chunk of SPH_CHUNK filter entries {p', W}, the bounding balls of its groups and of its runs of RT_SUPER
 // spheres, each array followed by FA_LDS_SLACK never-pass entries for the GROUP loops'
 // read-ahead.  Scenes with more than one chunk also stage the chunks' own balls, GRP_CHUNK at a
 // time, in the groups' array before they walk the chunks those select.
@@ -461,39 +448,30 @@ struct CandidateWalk {
 };
 
 // Filter entries of spheres [base, base + count) and their balls (count: a multiple of RT_SUPER).
-// CAMERA: entries become camera terms for the origin whose operands are fo's.
-template <bool CAMERA>
-__device__ __forceinline__ void stage_chunk(WalkLds &L, const DevScene &s, const FilterOrigin &fo, int base, int count)
+__device__ __forceinline__ void stage_chunk(WalkLds &L, const DevScene &s, int base, int count)
 {
     const float4 never = make_float4(0.f, 0.f, 0.f, -INFINITY);
     for (int i = threadIdx.x; i < count; i += blockDim.x)
-        L.sph[i] = CAMERA ? camera_term(s.sph_f[base + i], fo.lane) : s.sph_f[base + i];
+        L.sph[i] = s.sph_f[base + i];
     const int ng = count / RT_GROUP;
     for (int i = threadIdx.x; i < ng; i += blockDim.x)
-        L.grp[i] = CAMERA ? camera_term(s.grp_f[base / RT_GROUP + i], fo.lane_g) : s.grp_f[base / RT_GROUP + i];
+        L.grp[i] = s.grp_f[base / RT_GROUP + i];
     if (threadIdx.x < FA_LDS_SLACK) L.grp[ng + threadIdx.x] = never;
     // Coarse balls: padded to whole trips (the source array is padded the same way).
     const int ns = count / RT_SUPER;
     if ((int)threadIdx.x < SUP_LDS_ENTRIES) {
         float4 e = never;
-        if ((int)threadIdx.x < ns) {
-            e = s.sup_f[base / RT_SUPER + threadIdx.x];
-            if (CAMERA) e = camera_term(e, fo.lane_s);
-        }
+        if ((int)threadIdx.x < ns) e = s.sup_f[base / RT_SUPER + threadIdx.x];
         L.sup[threadIdx.x] = e;
     }
 }
 
 // Balls [first, first + count) of the chunks (count: a multiple of FA_TRIP, at most GRP_CHUNK).
-template <bool CAMERA>
-__device__ __forceinline__ void stage_chunk_balls(WalkLds &L, const DevScene &s, const f4raw lane_c, int first, int count)
+__device__ __forceinline__ void stage_chunk_balls(WalkLds &L, const DevScene &s, int first, int count)
 {
     for (int i = threadIdx.x; i < count + FA_LDS_SLACK; i += blockDim.x) {
         float4 e = make_float4(0.f, 0.f, 0.f, -INFINITY);
-        if (i < count) {
-            e = s.chk_f[first + i];
-            if (CAMERA) e = camera_term(e, lane_c);
-        }
+        if (i < count) e = s.chk_f[first + i];
         L.grp[i] = e;
     }
     if (threadIdx.x < GRP_WORDS) L.wg_bits[threadIdx.x] = 0u;
@@ -841,7 +819,7 @@ __device__ __forceinline__ void for_each_chunk(WalkLds &L, const DevScene &s, co
     for (int first = 0; first < nchk_padded; first += GRP_CHUNK) {
         const int n = min(GRP_CHUNK, nchk_padded - first);
         __syncthreads();   // whoever still reads the staged arrays is done
-        stage_chunk_balls<!TRACE>(L, s, lane_c, first, n);
+        stage_chunk_balls(L, s, first, n);
         __syncthreads();
         int i = 0;
         unsigned addr = lds_offset(L.grp), qaddr = lds_offset(L.cand) + 4u * threadIdx.x;
@@ -917,18 +895,81 @@ __device__ __forceinline__ f3 primary_direction(const DevCamera &cam, int px, in
 }
 
 // ---------------------------------------------------------------------------------------
+// Cone culling for primary rays.
+//
+// The 256 rays of a wave (a 16x16 pixel tile) leave one point o in nearly one direction.  Let a
+// be one of them and beta >= the angle between a and any of the others (measured on the rays
+// themselves: beta = 2 asin(chord / 2) of the longest chord |d_k - a|, widened).  If the
+// reference accepts (ray, sphere i) then, with D = |o - p_i| (see "Bounding balls" above): the
+// distance of p_i from the ray's line is at most R_i = sqrt(r_i^2 + 28.6u D^2) and the centre is
+// at most 4.1u D behind the origin; so either D <= R_i (to within 1e-6: the origin is inside) or
+// the angle between d and p_i - o is at most asin(R_i / D), and then the angle between a and
+// p_i - o is at most beta + asin(R_i / D).  The same holds for a ball (P, R) around spheres with
+// |p_i - P| + r_i <= R and the radius R' = R + 1.31e-3 (|o - P| + R) >= R + (R_i - r_i): the
+// ray's forward half-line comes within R' of P.  Hence a sphere or ball whose centre direction
+// v = P - o has  a.v < cos(beta) sqrt(|v|^2 - R'^2) - sin(beta) R'  (and |v| > R') is met by no
+// ray of the wave.  One LANE tests one ball or sphere: 64 of them per step, against the few
+// instructions of the test, instead of every lane testing every ball with its own rays; the
+// spheres that pass (a handful per tile) go to the exact, literal Sphere.Intersect of all 256
+// rays.  Evaluation margins: the test is made in FP32 on the scene's own coordinates, so v is an
+// exactly rounded difference; 1e-5 |v| on the right-hand side, 1e-5 rad on beta and 0.1 % on
+// "inside" are far above the sum of the roundings (about 20u |v|).  Anything not
+// finite passes; a sphere with non-finite data or r*r < 0 (padding) is never hit by the reference
+// and is skipped.  A ball or sphere every point of which is farther away than the wave's farthest
+// closest hit so far cannot change any ray's result either.
+// ---------------------------------------------------------------------------------------
+struct TileCone {
+    f3 a;
+    float cosb, sinb;   // bounds: cosb <= cos(beta), sinb >= sin(beta)
+    float chord;        // >= |d_k - a| for every ray of the wave
+    bool open;          // no usable cone (degenerate camera): everything passes
+};
+
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// v = centre - origin, R = the (already widened) radius; far = every ray of the wave has a hit
+// at t <= far.
+__device__ __forceinline__ bool cone_meets(const TileCone &tc, const f3 v, const float R, const float far)
+{
+    const float D2 = __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x));
+    const float D = __builtin_amdgcn_sqrtf(D2);
+    const float h2 = __builtin_fmaf(-R, R, D2);
+    const bool inside = !(h2 > 2e-3f * D2);                      // D <= 1.001 R, or not finite
+    const float c = __builtin_fmaf(tc.a.z, v.z, __builtin_fmaf(tc.a.y, v.y, tc.a.x * v.x));
+    const float bound = (tc.cosb * __builtin_amdgcn_sqrtf(h2) - tc.sinb * R) - 1e-5f * D;
+    const bool miss = c < bound;                                  // false when anything is NaN
+    const bool beyond = (D - R) * 0.999f > far;
+    return (tc.open || inside || !miss) && !beyond;
+}
+
+// A bounding ball {P, R}: widened by 1.5e-3 (|o - P| + R), see above.
+__device__ __forceinline__ bool ball_in_cone(const TileCone &tc, const float4 b, const f3 o, const float far)
+{
+    const f3 v = mk3(b.x - o.x, b.y - o.y, b.z - o.z);
+    const float D = __builtin_amdgcn_sqrtf(__builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
+    return cone_meets(tc, v, __builtin_fmaf(1.5e-3f, D + b.w, b.w), far);
+}
+
+// ---------------------------------------------------------------------------------------
 // primary: Raytracer.Render's loop body up to scene.Intersect (MyApplication.cs:412-415)
 // plus GetRayDirection (:428-452).  Each lane owns a 2x2 pixel quad, a wave 16x16 pixels, a
-// workgroup 32x32: one LDS read of a sphere feeds four rays, which keeps the LDS pipe (one
-// ds_read_b128 per 4 cycles per CU) well below the VALU time it has to feed.  Workgroups
-// are persistent so the spheres are staged once per workgroup.
+// workgroup 32x32.  The wave finds the spheres its tile's cone can meet by walking the
+// bounding balls one lane per ball (chunks, then runs of RT_SUPER spheres, then the 64 spheres
+// of a run), and every lane evaluates those spheres exactly for its four rays.
 // ---------------------------------------------------------------------------------------
 #define PRIM_PX 4   // pixels per lane (2x2)
 
-template <bool MULTI>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_primary(DevScene s, DevCamera cam, DevFrame f, int32_t *pixels)
+#ifndef RT_PRIMARY_WAVES
+#define RT_PRIMARY_WAVES 5
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_PRIMARY_WAVES)))
+k_primary(DevScene s, DevCamera cam, DevFrame f, int32_t *pixels)
 {
-    __shared__ WalkLds L;
     __shared__ int blk[12];
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -936,19 +977,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     const int tiles_x = (cam.width + 31) >> 5, tiles_y = (rows + 31) >> 5;
     const int ntiles = tiles_x * tiles_y;
     const int nsp = s.ns_padded;
+    const int nchk = (nsp + RT_CHUNK - 1) / RT_CHUNK, nsup = nsp / RT_SUPER;
     const f3 o = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
-    const FilterOrigin fo = filter_origin(s, o);
-    if (!MULTI) {
-        stage_chunk<true>(L, s, fo, 0, nsp);
-        __syncthreads();
-    }
-    FilterWork fw = {0, 0, 0};
-    PhaseClock pc = {};
-    const unsigned all_live[4] = {~0u, ~0u, ~0u, ~0u};
+    int cone_tests = 0, candidates = 0;   // steps of 64 cone tests (wave-uniform); exact calls (this lane's)
+    // A scene of one chunk: its 16 balls stay in registers (lane = ball) for every tile.
+    const float4 no_ball = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    const float4 only_chunk = nchk == 1 && lane < RT_CHUNK / RT_SUPER && lane < nsup ? s.sup_b[lane] : no_ball;
     // A workgroup's first tile is its index; the others are claimed from a counter (tiles cost
     // very different amounts), each claim sent before the tile it follows so that its answer
     // travels while that tile is traced.  blk[10], blk[11]: the answer, alternating per trip.
     int trip = 0;
+#ifdef RT_PRIMARY_CLOCKS
+    unsigned long long pclk[8] = {}, ptl = __builtin_readcyclecounter();
+#define PMARK(p) { const unsigned long long now_ = __builtin_readcyclecounter(); pclk[p] += now_ - ptl; ptl = now_; }
+#else
+#define PMARK(p)
+#endif
     for (int tile = blockIdx.x; tile < ntiles; trip++) {
         int claimed = 0;
         if (threadIdx.x == 0) claimed = (int)gridDim.x + atomicAdd(&f.sched->next_primary, 1);
@@ -959,7 +1003,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
         int px[PRIM_PX], py[PRIM_PX], ly[PRIM_PX];
         f3 d[PRIM_PX];
         float a[PRIM_PX], best_t[PRIM_PX];
-        int best_prim[PRIM_PX];   // host index of the closest sphere so far
+        int best_prim[PRIM_PX];   // host index of the closest primitive so far
 #pragma unroll
         for (int k = 0; k < PRIM_PX; k++) {
             const int x = x0 + (k & 1), y = y0 + (k >> 1);
@@ -973,13 +1017,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
             best_t[k] = RT_FLT_MAX;
             best_prim[k] = INT_MAX;
         }
-        f4raw rq[4];
+        PMARK(0)
+        // The tile's cone: axis = the ray next to the tile's centre, beta from the longest chord.
+        TileCone tc;
+        tc.a = mk3(__shfl(d[0].x, 36), __shfl(d[0].y, 36), __shfl(d[0].z, 36));
+        {
+            float ch2 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < PRIM_PX; k++) rq[k] = filter_ray(fo, d[k]);
+            for (int k = 0; k < PRIM_PX; k++) {
+                const f3 e = sub3(d[k], tc.a);
+                const float q = __builtin_fmaf(e.z, e.z, __builtin_fmaf(e.y, e.y, e.x * e.x));
+                ch2 = q > ch2 || q != q ? q : ch2;   // (a NaN chord sticks)
+            }
+            float chord = __builtin_amdgcn_sqrtf(ch2);
+            const unsigned long long bad = __ballot(chord != chord);
+            chord = wave_max_f(chord);
+            tc.chord = chord;
+            // 2 asin(c / 2) <= c (1 + c*c / 6) for c <= 1.4
+            const float beta = chord * __builtin_fmaf(chord * chord, 1.0f / 6.0f, 1.0f) * 1.00001f + 1e-5f;
+            tc.open = bad != 0ull || !(beta <= 1.0f);
+            tc.sinb = beta;                                        // sin(beta) <= beta
+            tc.cosb = __builtin_fmaf(-0.5f * beta, beta, 1.0f) - 1e-7f;   // cos(beta) >= 1 - beta*beta / 2
+        }
+        PMARK(1)
         // Exact evaluation of a candidate: objects.cs:112-121 literally; among equal
         // distances the lower host index wins, as the strict `<` of MyApplication.cs:361
         // decides when the primitives are scanned in host order.
-        auto exact = [&](auto, const float4 sp, const int orig) {
+        auto exact = [&](const float4 sp, const int orig) {
             const f3 op = sub3(o, xyz(sp));
             const float c = dot3(op, op) - sp.w;
 #pragma unroll
@@ -993,64 +1057,135 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
                 }
             }
         };
-        if constexpr (!MULTI) {
-            if (nsp > 0)
-                walk_chunk<PRIM_PX, false, false>(L, nsp, s.sph, s.sph_orig, rq, fo.lane_s, fo.lane_g, fo.lane, fw, pc,
-                                                  exact, all_live);
-        } else {
-            for_each_chunk<PRIM_PX, false, false>(L, s, rq, fo.lane_c, fo.oc, fw, all_live,
-                                                  [&](const float4 ball) {
-                const float far_t = fmaxf(fmaxf(best_t[0], best_t[1]), fmaxf(best_t[2], best_t[3]));
-                return ball_within_reach(s, fo, ball, far_t);
-            },
-                                                  [&](const int base, const int cnt) {
-                __syncthreads();
-                stage_chunk<true>(L, s, fo, base, cnt);
-                __syncthreads();
-                walk_chunk<PRIM_PX, false, false>(L, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_s, fo.lane_g,
-                                                  fo.lane, fw, pc, exact, all_live);
-            });
+        float far = RT_FLT_MAX;   // every ray of the wave has its closest hit at t <= far
+#pragma clang loop unroll(disable)
+        for (int c0 = 0; c0 < nchk; c0 += 64) {
+            unsigned long long cm = 1ull;
+            if (nchk > 1) {
+                bool cpass = false;
+                if (c0 + lane < nchk) {
+                    const float4 b = s.chk_b[c0 + lane];
+                    cpass = b.w >= 0.0f && ball_in_cone(tc, b, o, far);
+                }
+                cone_tests++;
+                cm = __ballot(cpass);
+            }
+#pragma clang loop unroll(disable)
+            while (cm != 0ull) {
+                const int chunk = c0 + (__ffsll((long long)cm) - 1);
+                cm &= cm - 1ull;
+                // the chunk's runs of RT_SUPER spheres: RT_CHUNK / RT_SUPER = 16 balls, lanes 0..15
+                const int si = chunk * (RT_CHUNK / RT_SUPER) + lane;
+                float4 b = only_chunk;
+                if (nchk > 1 && lane < RT_CHUNK / RT_SUPER && si < nsup) b = s.sup_b[si];
+                const bool spass = b.w >= 0.0f && ball_in_cone(tc, b, o, far);
+                cone_tests++;
+                unsigned long long sm = __ballot(spass);
+                PMARK(2)
+#pragma clang loop unroll(disable)
+                while (sm != 0ull) {
+                    const int run = chunk * (RT_CHUNK / RT_SUPER) + (__ffsll((long long)sm) - 1);
+                    sm &= sm - 1ull;
+                    const int i = run * RT_SUPER + lane;   // (< ns_padded: a whole number of runs)
+                    const float4 sp = s.sph[i];
+                    const int orig = s.sph_orig[i];
+                    const f3 v = sub3(xyz(sp), o);
+                    const float D2 = __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x));
+                    // R_i^2 = r*r + 28.6u D^2, with room: 4e-6 D^2
+                    const float R = __builtin_amdgcn_sqrtf(__builtin_fmaf(4e-6f, D2, sp.w));
+                    const bool hpass = sp.w >= 0.0f && sp.w < INFINITY && cone_meets(tc, v, R, far);
+                    cone_tests++;
+                    unsigned long long hm = __ballot(hpass);
+                    PMARK(3)
+#pragma clang loop unroll(disable)
+                    while (hm != 0ull) {
+                        const int j = __ffsll((long long)hm) - 1;
+                        hm &= hm - 1ull;
+                        exact(make_float4(__shfl(sp.x, j), __shfl(sp.y, j), __shfl(sp.z, j), __shfl(sp.w, j)), __shfl(orig, j));
+                        candidates++;
+                    }
+                    PMARK(4)
+                }
+                if (nchk > 1) far = wave_max_f(fmaxf(fmaxf(best_t[0], best_t[1]), fmaxf(best_t[2], best_t[3])));
+            }
+        }
+        // Planes (Plane.Intersect objects.cs:157-164).  t = numer / denom decides only when it can
+        // still win: the quotient from the hardware reciprocal is within 1e-6 (relative) of the
+        // correctly rounded one, so a plane whose quotient is clearly behind the epsilon or clearly
+        // beyond the closest hit so far needs no divide.
+        // A plane that faces away from every ray of the tile is skipped for the whole wave: with
+        // c = n.a and |n.(d_k - a)| <= |n|_1 chord, all denominators n.d_k (and their FP32 values,
+        // off by at most 3u |n|_1) share the sign of c when |c| > |n|_1 (chord + 2e-6), and a
+        // quotient of opposite signs (or a zero numerator) is <= 0, which Plane.Intersect rejects.
+        for (int j = 0; j < s.np; j++) {
+            const float4 pl = cload(s.pl, j);
+            const f3 n = xyz(pl);
+            const float numer = (-dot3(n, o)) - pl.w;
+            const int orig = cload(s.pl_orig, j);
+            {
+                const float c = __builtin_fmaf(n.z, tc.a.z, __builtin_fmaf(n.y, tc.a.y, n.x * tc.a.x));
+                const float spread = ((fabsf(n.x) + fabsf(n.y)) + fabsf(n.z)) * (tc.chord * 1.001f + 2e-6f);
+                if (!tc.open && ((c > spread && numer <= 0.0f) || (c < -spread && numer >= 0.0f))) continue;
+            }
+#pragma unroll
+            for (int k = 0; k < PRIM_PX; k++) {
+                const float denom = dot3(n, d[k]);
+                if (fabsf(denom) <= 0.0001f) continue;
+                const float q = numer * __builtin_amdgcn_rcpf(denom);
+                if (q < RT_EPS * (1.0f - 1e-6f) || q * (1.0f - 1e-6f) > best_t[k]) continue;
+                const float t = ieee_div(numer, denom);
+                if (!(t <= 0.0001f) && t > RT_EPS && (t < best_t[k] || (t == best_t[k] && orig < best_prim[k]))) {
+                    best_t[k] = t;
+                    best_prim[k] = orig;
+                }
+            }
+        }
+        for (int j = 0; j < s.nt; j++) {
+            const f3 v0 = xyz(cload(s.tri, 3 * j)), e1 = xyz(cload(s.tri, 3 * j + 1)), e2 = xyz(cload(s.tri, 3 * j + 2));
+            const int orig = cload(s.tri_orig, j);
+            const f3 sv = sub3(o, v0);
+#pragma unroll
+            for (int k = 0; k < PRIM_PX; k++) {
+                float t;
+                if (triangle_t(e1, e2, sv, d[k], t) && t > RT_EPS &&
+                    (t < best_t[k] || (t == best_t[k] && orig < best_prim[k]))) {
+                    best_t[k] = t;
+                    best_prim[k] = orig;
+                }
+            }
         }
         bool rec_valid[PRIM_PX];
+        PMARK(5)
         int rec_prim[PRIM_PX], rec_parent[PRIM_PX];
         f3 rec_hit[PRIM_PX];
 #pragma unroll
         for (int k = 0; k < PRIM_PX; k++) {
-            Closest c;
-            c.t = best_t[k];
-            c.prim = best_prim[k];
-            for (int j = 0; j < s.np; j++) {
-                const float4 pl = cload(s.pl, j);
-                const f3 n = xyz(pl);
-                const float numer = (-dot3(n, o)) - pl.w;
-                float t;
-                if (plane_t(n, numer, d[k], t)) closest_offer(c, t, cload(s.pl_orig, j));
-            }
-            for (int j = 0; j < s.nt; j++) {
-                const f3 v0 = xyz(cload(s.tri, 3 * j)), e1 = xyz(cload(s.tri, 3 * j + 1)),
-                         e2 = xyz(cload(s.tri, 3 * j + 2));
-                float t;
-                if (triangle_t(e1, e2, sub3(o, v0), d[k], t)) closest_offer(c, t, cload(s.tri_orig, j));
-            }
-            const bool hit = inside[k] && c.prim != INT_MAX;
+            const bool hit = inside[k] && best_prim[k] != INT_MAX;
             const int pix = ly[k] * cam.width + px[k];
             rec_valid[k] = hit;
-            rec_prim[k] = hit ? c.prim : 0;
+            rec_prim[k] = hit ? best_prim[k] : 0;
             rec_parent[k] = pix;
-            rec_hit[k] = add3(o, scale3(d[k], c.t));
+            rec_hit[k] = add3(o, scale3(d[k], best_t[k]));
             if (inside[k] && !hit) pixels[pix] = 0;  // MyApplication.cs:423
         }
         if (threadIdx.x == 0) blk[10 + (trip & 1)] = claimed;
         push_records<PRIM_PX, false>(f, s, 0, blk, rec_valid, rec_prim, rec_hit, d, rec_parent);   // (barriers)
         tile = blk[10 + (trip & 1)];
+        PMARK(6)
     }
-    // Counter words in the order of DevCounters; the filter's counts are the same in every lane.
-    const unsigned long long cand_total = (unsigned long long)wave_sum(fw.candidates);
-    const unsigned long long tests = 64ull * (unsigned long long)fw.ray_tests;
+    // Counter words in the order of DevCounters: cone tests count as filter evaluations.
+    const unsigned long long cand_total = (unsigned long long)wave_sum(candidates);
+    const unsigned long long tests = 64ull * (unsigned long long)cone_tests;
+#ifdef RT_PRIMARY_CLOCKS
+    const unsigned long long v[COUNTER_WORDS] = {pclk[0], pclk[1], pclk[2], pclk[3], pclk[4], pclk[5], pclk[6], cand_total, tests};
+    flush_counters(f, cnt_sh, v);
+#else
     const unsigned long long v[COUNTER_WORDS] = {0ull, 0ull, 0ull, cand_total, tests, 0ull, tests, cand_total, 0ull};
 #ifndef RT_PHASE_CLOCKS
     flush_counters(f, cnt_sh, v);
 #endif
+#endif
+#undef PMARK
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1135,7 +1270,7 @@ __device__ __forceinline__ void traverse(const DevScene &s, WalkLds &L,
                                         [&](const float4 ball) { return !SEC || LC > 0 || ball_within_reach(s, fo, ball, best_t); },
                                         [&](const int base, const int cnt) {
             __syncthreads();
-            stage_chunk<false>(L, s, fo, base, cnt);
+            stage_chunk(L, s, base, cnt);
             __syncthreads();
             // A light ray that has met an occluder needs no further look at the scene unless the
             // caller wants the reference's Intersect-call counts, which depend on WHICH occluder
@@ -1641,7 +1776,7 @@ __global__ void __launch_bounds__(256) k_reflect(DevScene s, DevFrame f, int lev
     const int n = f.cnt[2 * level];
     const int ntiles = (n + 255) >> 8;
     if (!MULTI && (int)blockIdx.x < ntiles) {
-        stage_chunk<false>(L, s, FilterOrigin{}, 0, s.ns_padded);
+        stage_chunk(L, s, 0, s.ns_padded);
         __syncthreads();
     }
     TestCount tc = {0, 0, 0, 0, 0, 0, 0};
@@ -1829,7 +1964,7 @@ k_trace_levels(DevScene s, DevFrame f, int32_t *pixels)
         if (kind == SCHED_JOB_EXIT) break;
         // Only reflection rays walk the staged spheres: stage them before the first such tile.
         if (!MULTI && !staged && kind == SCHED_JOB_A) {
-            stage_chunk<false>(L, s, FilterOrigin{}, 0, s.ns_padded);
+            stage_chunk(L, s, 0, s.ns_padded);
             staged = true;
         }
         __syncthreads();   // job[] read by all, spheres staged
@@ -1893,6 +2028,11 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
 // wrap, texel = byte / 255) evaluated in FP32, operation by operation; colours go back to bytes
 // by round-to-nearest and the alpha byte stays 0 (texColor.a).  Bandwidth-bound: 4 bytes read
 // (neighbours come from cache) and 4 written per pixel.
+//
+// The filter follows, operation by operation, the FXAA routine of that shader, which is
+// Copyright (c) 2011 by Armin Ronacher (webgl-meincraft), some rights reserved, distributed under
+// a three-clause BSD licence; the notice, conditions and disclaimer are reproduced in
+// THIRD_PARTY_NOTICES.md at the root of this repository.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int fx_wrap(int i, int n)
 {
@@ -2036,8 +2176,7 @@ void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int
 {
     const int ntiles = ((cam.width + 31) / 32) * ((cam.rows + 31) / 32);  // 32x32 pixels per workgroup trip
     const dim3 g(ntiles < grid_blocks ? ntiles : grid_blocks), b(256);
-    if (multi_chunk(s)) hipLaunchKernelGGL(k_primary<true>, g, b, 0, stream, s, cam, f, pixels);
-    else hipLaunchKernelGGL(k_primary<false>, g, b, 0, stream, s, cam, f, pixels);
+    hipLaunchKernelGGL(k_primary, g, b, 0, stream, s, cam, f, pixels);
 }
 
 void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting, int32_t *pixels, int grid_blocks,

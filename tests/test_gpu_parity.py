@@ -481,6 +481,27 @@ def test_two_device_states_split_rows_and_gather(oracle):
             assert np.array_equal(gpu, ref), (w, h)
 
 
+def test_devices_without_peer_access_hand_their_rows_over_through_the_host(oracle, monkeypatch):
+    """The gather of a context whose other devices cannot write into the first one's memory: their
+    rows travel through the page-locked staging frame (RT_HIP_NO_PEER=1 makes rt_create treat every
+    other device that way).  Interleaved bands and the contiguous fallback, two and three devices."""
+    monkeypatch.setenv("RT_HIP_NO_PEER", "1")
+    fs = default_scene().flatten()
+    cam = Camera(position=(0.3, 0.1, -0.2))
+    with RenderContext([0, 0]) as two:
+        two.set_scene(fs)
+        for (w, h) in [(200, 150), (64, 33)]:
+            gpu = two.render(cam, w, h, 5)
+            ref, _ = oracle.render(fs, cam, w, h, max_depth=5)
+            assert np.array_equal(gpu, ref), (w, h)
+        assert two.stats()["num_devices"] == 2
+    with RenderContext([0, 0, 0]) as three:
+        three.set_scene(fs)
+        gpu = three.render(cam, 120, 161, 5)
+        ref, _ = oracle.render(fs, cam, 120, 161, max_depth=5)
+        assert np.array_equal(gpu, ref)
+
+
 def test_pipeline_with_a_context_per_slot_renders_frames_side_by_side(oracle):
     """FramePipeline built with one render context per slot: the slots' frames render at the same
     time on streams of their own (each context sized for a third of the device) and every frame
