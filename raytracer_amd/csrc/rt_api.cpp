@@ -1086,6 +1086,23 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // tile is never counted as done, which stalls the schedule there on purpose.
     const char *withhold_env = getenv("RT_HIP_DEBUG_WITHHOLD_LEVEL");
     fr.debug_withhold = withhold_env ? atoi(withhold_env) : -1;
+    const char *pipeline_env = getenv("RT_HIP_PIPELINE");   // (read at every call; see below)
+    static const bool level_kernels = getenv("RT_HIP_LEVEL_KERNELS") != nullptr;
+    const bool fused = pipeline_env ? strcmp(pipeline_env, "fused") == 0
+                                    : !level_kernels && tiles0 < RT_FUSED_BELOW_TILES_PER_WORKGROUP * resident(false);
+    // Scenes of several chunks, one launch per level: the reflection rays of a level are traced as
+    // (tile, chunk) jobs (k_reflect_chunks).  RT_HIP_SPLIT_CHUNKS=0 (tuning aid) keeps a tile's chunks
+    // to its own workgroup.
+    static const bool split_env = !getenv("RT_HIP_SPLIT_CHUNKS") || atoi(getenv("RT_HIP_SPLIT_CHUNKS")) != 0;
+    fr.split_chunks = !fused && split_env && d.scene.ns_padded > RT_CHUNK ? 1 : 0;
+    static const int split_below_env = getenv("RT_HIP_SPLIT_BELOW") ? atoi(getenv("RT_HIP_SPLIT_BELOW")) : 0;
+    fr.split_below = split_below_env > 0 ? split_below_env : std::max(1, d.num_cus * 2 / share);
+    // Scenes with several lights, one launch per level: short queues are shaded with the lights spread
+    // over the waves of a workgroup (k_shade_lights).  RT_HIP_LIGHT_SPLIT_BELOW=n (tuning aid; 0 = never).
+    static const int light_below_env = getenv("RT_HIP_LIGHT_SPLIT_BELOW") ? atoi(getenv("RT_HIP_LIGHT_SPLIT_BELOW")) : -1;
+    const int nl = d.scene.nl;
+    fr.light_waves = fused || nl < 3 || light_below_env == 0 ? 0 : nl >= 12 ? 16 : nl >= 6 ? 8 : 4;
+    fr.light_split_below = light_below_env > 0 ? light_below_env : 64 * 1024 / share;
     d.last_stream = stream;
     const DevFrame &f = fr;
     if (part > 0) HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, FRAME_CONTROL_BYTES - RT_COUNTER_SLOTS * sizeof(DevCounters), stream));
@@ -1109,14 +1126,11 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // levels of a small frame, but plain records then run at the walk kernel's occupancy.
     // RT_HIP_PIPELINE=levels|fused (tuning aid) overrides; RT_HIP_LEVEL_KERNELS=1 (profiling aid)
     // is "levels" on ONE stream, so that a kernel trace shows what each launch costs on its own.
-    const char *pipeline_env = getenv("RT_HIP_PIPELINE");   // (read at every call)
-    static const bool level_kernels = getenv("RT_HIP_LEVEL_KERNELS") != nullptr;
-    const bool fused = pipeline_env ? strcmp(pipeline_env, "fused") == 0
-                                    : !level_kernels && tiles0 < RT_FUSED_BELOW_TILES_PER_WORKGROUP * resident(false);
     if (!fused) {
         // (counting kernels add to per-workgroup counter slots without atomics: one stream then)
         const bool two_streams = !level_kernels && !counting && max_depth > 0;
         const int plain_blocks = std::max(1, std::min({tiles0, d.num_cus * 16 / share, RT_COUNTER_SLOTS}));
+        const int light_blocks = std::max(1, std::min(d.num_cus * 8 / share, RT_COUNTER_SLOTS));
         hipStream_t chain = two_streams ? d.aux : stream;
         if (two_streams) {
             HIP_TRY(ctx, hipEventRecord(d.ev_fork, stream));
@@ -1125,10 +1139,12 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
         for (int k = 0; k <= max_depth; k++) {
             if (k < max_depth) {
                 rtk_trace(d.scene, f, k, true, dev_pixels, blocks, chain);
+                if (f.split_chunks) rtk_reflect_chunks(d.scene, f, k, std::max(1, d.num_cus * 4 / share), blocks, chain);
                 if (two_streams) HIP_TRY(ctx, hipEventRecord(d.ev_level[k], d.aux));
             }
             if (two_streams && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(stream, d.ev_level[k - 1], 0));
             rtk_trace(d.scene, f, k, false, dev_pixels, plain_blocks, stream);
+            if (f.light_waves) rtk_shade_lights(d.scene, f, k, false, dev_pixels, light_blocks, stream);
         }
     } else {
         // Every level in one launch of resident workgroups (k_trace_levels).
@@ -1139,8 +1155,11 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // (measured at 3840x2160: 0.128 ms against 0.145 with 8 and 0.143 with 128).
     const int shade_blocks = std::max(1, std::min((P + 255) / 256, d.num_cus * 32));
     // (the reflecting records; the deepest level has none)
-    for (int k = max_depth - 1; k >= 0; k--)
+    for (int k = max_depth - 1; k >= 0; k--) {
         rtk_shade_level(d.scene, f, k, dev_pixels, std::min(shade_blocks, RT_COUNTER_SLOTS), stream);
+        if (f.light_waves)
+            rtk_shade_lights(d.scene, f, k, true, dev_pixels, std::max(1, std::min(d.num_cus * 8 / share, RT_COUNTER_SLOTS)), stream);
+    }
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[3], stream));
     if (part >= 0)
         HIP_TRY(ctx, hipMemcpyAsync(d.outcome_snap + (size_t)part * FRAME_OUTCOME_BYTES, f.sched, FRAME_OUTCOME_BYTES,

@@ -182,6 +182,11 @@ struct DevFrame {
     int *status;
     unsigned stall_ticks;  // how long a workgroup waits without progress, in ticks of the 100 MHz wall clock
     int debug_withhold;    // test knob: the first reflecting tile of this level is never counted as done (-1: off)
+    int light_waves;       // > 0: queues of fewer than light_split_below records are shaded with the lights spread
+    int light_split_below; // over that many waves per 64 records (k_shade_lights)
+    int split_chunks;      // 1: levels with fewer than split_below reflecting tiles are traced one (tile, chunk)
+    int split_below;       // job at a time (k_reflect_chunks): new reflecting records get their closest-hit word
+                           // initialised in refl[]
 };
 
 // Launch wrappers (rt_kernels.hip).  All enqueue on `stream` and return at once.
@@ -190,6 +195,9 @@ void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int
 // reflecting: the level's records that need a reflection trace (queue A) or the others (B).
 void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting, int32_t *pixels, int grid_blocks,
                hipStream_t stream);
+// The reflecting records of a level of a many-chunk scene as (tile, chunk) jobs, then the pass that
+// completes them (planes, triangles, next level's records).  Needs DevFrame::split_chunks.
+void rtk_reflect_chunks(const DevScene &s, const DevFrame &f, int level, int job_blocks, int tile_blocks, hipStream_t stream);
 // Every level in one launch; grid_blocks = workgroups resident at once on the device
 // (rtk_trace_levels_resident_blocks), fewer if the frame has fewer tiles.
 // (of the instance rtk_trace_levels launches for a frame with that chain policy / counting mode)
@@ -197,6 +205,10 @@ int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus, bool reserv
 void rtk_trace_levels(const DevScene &s, const DevFrame &f, int32_t *pixels, int grid_blocks, hipStream_t stream);
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
                      int grid_blocks, hipStream_t stream);
+// The plain (reflecting = false) or reflecting records of a level, lights spread over DevFrame::light_waves
+// waves per 64 records; does nothing unless the queue is shorter than DevFrame::light_split_below.
+void rtk_shade_lights(const DevScene &s, const DevFrame &f, int level, bool reflecting, int32_t *pixels, int grid_blocks,
+                      hipStream_t stream);
 // Raytracer.Debug's rays: 16 floats per ray (rt_debug_ray's 14 words, then two of padding).
 void rtk_debug_rays(const DevScene &s, const DevCamera &cam, int row, int x_step, int count, float *out,
                     hipStream_t stream);

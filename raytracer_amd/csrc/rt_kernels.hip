@@ -285,6 +285,13 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
                 f.recA[slot] = make_float4(hit[k].x, hit[k].y, hit[k].z, __int_as_float(prim[k]));
                 f.recB[slot] = make_float4(view[k].x, view[k].y, view[k].z, __int_as_float(parent[k]));
             }
+            // Frames whose reflection rays are traced chunk by chunk (k_reflect_chunks) keep the
+            // closest hit so far in the first two words of the record's refl slot: nothing yet.
+            if (f.split_chunks && is_a[k]) {
+                const float none = __uint_as_float(0xffffffffu);
+                if (THROUGH) store_record(&f.refl[slot], f4raw{none, none, 0.0f, 0.0f});
+                else f.refl[slot] = make_float4(none, none, 0.0f, 0.0f);
+            }
         }
     }
     __syncthreads();  // blk may be reused by the caller's next trip
@@ -1421,11 +1428,25 @@ __device__ __forceinline__ bool plane_occludes(const f3 n, const float numer, co
 #endif //   // table entries per lane in flight together
 
 template <bool COUNT>
-__device__ __forceinline__ int light_occluder(const DevScene &s, const int l, const f3 hit, const f3 lp, const f3 d,
+__device__ __forceinline__ int light_occluder(const DevScene &s, const uint2 cell, const f3 hit, const f3 d,
                                               const float a, const float dist, const bool far, const bool any_far,
                                               const bool active, TestCount &tc)
 {
     int first = INT_MAX;
+    // The list's first entries are fetched before the planes and triangles are tested, so that their
+    // way from memory is covered by that arithmetic (cell: the light's table cell for this origin,
+    // which the caller fetched while it shaded the previous light).
+    const float4 none = make_float4(0.f, 0.f, 0.f, -INFINITY);   // never occludes
+    const float4 *list = s.lt_sph + cell.x;
+    const float *reach = s.lt_reach + cell.x;
+    const int cnt0 = s.lt_n > 0 && active && !far ? (int)cell.y : 0;
+    float4 nxt[LIGHT_BATCH];
+    float nxt_reach[LIGHT_BATCH];
+#pragma unroll
+    for (int j = 0; j < LIGHT_BATCH; j++) {
+        nxt[j] = j < cnt0 ? list[j] : none;
+        nxt_reach[j] = j < cnt0 ? reach[j] : 0.0f;
+    }
     for (int j = 0; j < s.np; j++) {
         const float4 pl = cload(s.pl, j);
         const f3 n = xyz(pl);
@@ -1437,23 +1458,12 @@ __device__ __forceinline__ int light_occluder(const DevScene &s, const int l, co
         if (triangle_t(e1, e2, sub3(hit, v0), d, t) && t > RT_EPS && t < dist) first = min(first, cload(s.tri_orig, j));
     }
     if (s.lt_n > 0) {
-        const uint2 cell = light_table_cell(s, l, sub3(hit, lp));
-        int cnt = !active || far || (!COUNT && first != INT_MAX) ? 0 : (int)cell.y;
-        const float4 *list = s.lt_sph + cell.x;
+        int cnt = !COUNT && first != INT_MAX ? 0 : cnt0;
         // LIGHT_BATCH entries per step, the next step's loads in flight while this step's entries are
         // evaluated: a list is walked at the pace of the arithmetic, not of one memory round trip
         // per entry.
         // A list is sorted by how close its spheres come to the light (lt_reach): the first one that
         // stays farther from the light than the ray's own origin ends the walk.
-        const float4 none = make_float4(0.f, 0.f, 0.f, -INFINITY);   // never occludes
-        const float *reach = s.lt_reach + cell.x;
-        float4 nxt[LIGHT_BATCH];
-        float nxt_reach[LIGHT_BATCH];
-#pragma unroll
-        for (int j = 0; j < LIGHT_BATCH; j++) {
-            nxt[j] = j < cnt ? list[j] : none;
-            nxt_reach[j] = j < cnt ? reach[j] : 0.0f;
-        }
 #pragma clang loop unroll(disable)
         for (int k = 0; __ballot(k < cnt) != 0ull; k += LIGHT_BATCH) {
             float4 sp[LIGHT_BATCH];
@@ -1592,90 +1602,106 @@ __device__ __forceinline__ f3 texture_color(const DevScene &s, int slot, f3 hit)
 __device__ __forceinline__ float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 
 
+// What Shade needs of a record before it looks at the lights.
+struct ShadeRecord {
+    f3 hit, view, normal;
+    f3 base;          // surface colour under a light: material, texture or checkerboard (objects.cs:62-74)
+    f3 mat_glossy, mat_ambient;
+    f3 refl_term;     // (Vector4)Shade(child) * material.specular * 1, when have_refl
+    bool have_refl;   // the record traced a reflection ray that hit something (objects.cs:80-88)
+    bool far;         // the origin lies outside the region the lights' tables serve
+    bool any_far;     // ... some active lane's of this wave does
+    int parent;
+};
+
 // reflecting: the record is in its level's queue A (it traced a reflection ray, and refl[slot]
 // holds the child's colour if that ray hit something).  through: the record was written earlier
 // in this launch by another workgroup (device-scope loads).  Every lane of the wave must call it.
-template <bool COUNT>
-__device__ __forceinline__ void shade_record(const DevScene &s, const DevFrame &f, const int level, const int slot,
-                                             const bool active, const bool reflecting, const bool through,
-                                             int32_t *pixels, TestCount &tc)
+__device__ __forceinline__ ShadeRecord shade_setup(const DevScene &s, const DevFrame &f, const int slot,
+                                                   const bool active, const bool reflecting, const bool through)
 {
+    ShadeRecord r;
     float4 ra, rb;
     if (through) load_record(&f.recA[slot], &f.recB[slot], ra, rb);
     else ra = f.recA[slot], rb = f.recB[slot];
-    const f3 hit = xyz(ra), view = xyz(rb);
-    const int prim = __float_as_int(ra.w), parent = __float_as_int(rb.w);
+    r.hit = xyz(ra);
+    r.view = xyz(rb);
+    const int prim = __float_as_int(ra.w);
+    r.parent = __float_as_int(rb.w);
     const float4 m0 = cload(s.mat, 3 * prim), m1 = cload(s.mat, 3 * prim + 1), m2 = cload(s.mat, 3 * prim + 2);
     const int flags = __float_as_int(m1.w);
     const int type = flags & RT_MF_TYPE_MASK;
-    const f3 normal = record_normal(s, prim, type, hit);
+    r.normal = record_normal(s, prim, type, r.hit);
     const float specular = m0.w;
-    const f3 mat_glossy = xyz(m1), mat_ambient = xyz(m2);
-
-    // Surface colour under the light: material, texture or checkerboard
-    // (objects.cs:62-74); the same for every light, so looked up once.
-    f3 base = xyz(m0);
+    r.mat_glossy = xyz(m1);
+    r.mat_ambient = xyz(m2);
+    // The same for every light, so looked up once.
+    r.base = xyz(m0);
     if (type == 1) {
         const int tex = (flags & RT_MF_TEX_MASK) >> RT_MF_TEX_SHIFT;
-        if (tex != 0) base = texture_color(s, tex - 1, hit);
+        if (tex != 0) r.base = texture_color(s, tex - 1, r.hit);
         else if (flags & RT_MF_CHECKER) {
-            const float cw = checker_white(hit) ? 1.0f : 0.0f;
-            base = mk3(cw, cw, cw);
+            const float cw = checker_white(r.hit) ? 1.0f : 0.0f;
+            r.base = mk3(cw, cw, cw);
         }
     }
-    // Reflected colour (objects.cs:80-88): present when this record traced a
-    // reflection ray that hit something.
-    bool have_refl = false;
-    f3 refl_term = mk3(0.0f, 0.0f, 0.0f);
+    r.have_refl = false;
+    r.refl_term = mk3(0.0f, 0.0f, 0.0f);
     if (reflecting) {
         const float4 rf = f.refl[slot];
-        have_refl = rf.w != 0.0f;
-        // (Vector4)Shade(..) * material.specular * 1
-        refl_term = scale3(scale3(xyz(rf), specular), 1.0f);
+        r.have_refl = rf.w != 0.0f;
+        r.refl_term = scale3(scale3(xyz(rf), specular), 1.0f);
     }
     // Does the lights' tables' region hold this origin?  (A NaN origin is "far" and then meets
     // nothing, like in the reference.)
-    const f3 oc = mk3(hit.x - s.sph_center[0], hit.y - s.sph_center[1], hit.z - s.sph_center[2]);
-    const bool far = s.lt_n > 0 && !(((fabsf(oc.x) + fabsf(oc.y)) + fabsf(oc.z)) <= s.lt_near);
-    const bool any_far = s.lt_n > 0 && __ballot(active && far) != 0ull;
+    const f3 oc = mk3(r.hit.x - s.sph_center[0], r.hit.y - s.sph_center[1], r.hit.z - s.sph_center[2]);
+    r.far = s.lt_n > 0 && !(((fabsf(oc.x) + fabsf(oc.y)) + fabsf(oc.z)) <= s.lt_near);
+    r.any_far = s.lt_n > 0 && __ballot(active && r.far) != 0ull;
+    return r;
+}
 
-    f3 final = mk3(0.0f, 0.0f, 0.0f);
-    const int nl = s.nl;
-    for (int l = 0; l < nl; l++) {
-        const f3 lp = xyz(cload(s.light_pos, l)), lc = xyz(cload(s.light_col, l));
-        const f3 to_light = sub3(lp, hit);
-        const f3 shadow_ray = normalized3(to_light);            // objects.cs:51
-        const float distance = length3(to_light);               // objects.cs:52
-        float diffuse = net_maxf(dot3(normal, shadow_ray), 0.0f);
-        float glossy = 1.0f;
-        // IsInShadow(hitPoint, shadowRay, 0.0001f, distance), objects.cs:56
-        const int occluder = light_occluder<COUNT>(s, l, hit, lp, shadow_ray, dot3(shadow_ray, shadow_ray), distance,
-                                                   far, any_far, active, tc);
-        if (occluder != INT_MAX) {
-            diffuse = 0.0f;
-            glossy = 0.0f;
-        }
-        const f3 diffuse_color = scale3(base, diffuse);
-        const f3 reflection = sub3(shadow_ray, scale3(normal, 2.0f * dot3(shadow_ray, normal)));
-        const float sp = pow250(net_maxf(dot3(reflection, view), 0.0f));
-        const f3 glossy_color = scale3(scale3(mat_glossy, sp), glossy);
-        const float d2 = distance * distance;
-        if (have_refl) {
-            final = add3(final, mk3(ieee_div(refl_term.x, d2), ieee_div(refl_term.y, d2),
-                                    ieee_div(refl_term.z, d2)));
-        }
-        // light.color * 1 / (distance*distance) * (diffuseColor + glossyColor) + ambient
-        // (per component; the reference's lights are (2, 2, 2): equal components share the quotient)
-        f3 li;
-        li.x = ieee_div(lc.x * 1.0f, d2);
-        if (lc.y == lc.x && lc.z == lc.x) li.y = li.z = li.x;   // wave-uniform
-        else li.y = ieee_div(lc.y * 1.0f, d2), li.z = ieee_div(lc.z * 1.0f, d2);
-        const f3 dg = add3(diffuse_color, glossy_color);
-        const f3 term = add3(mk3(li.x * dg.x, li.y * dg.y, li.z * dg.z), mat_ambient);
-        final = add3(final, term);
+// One pass of the reference's light loop (objects.cs:51-91) for light l: what it adds to finalColor,
+// in its order: first `reflected` (only when the record has a reflected colour), then `direct`.
+// cell: the light's table cell for this origin (light_table_cell).  Every lane of the wave must call it.
+template <bool COUNT>
+__device__ __forceinline__ void light_terms(const DevScene &s, const ShadeRecord &r, const int l, const uint2 cell,
+                                            const bool active, TestCount &tc, f3 &reflected, f3 &direct)
+{
+    const f3 lp = xyz(cload(s.light_pos, l)), lc = xyz(cload(s.light_col, l));
+    const f3 to_light = sub3(lp, r.hit);
+    const f3 shadow_ray = normalized3(to_light);            // objects.cs:51
+    const float distance = length3(to_light);               // objects.cs:52
+    float diffuse = net_maxf(dot3(r.normal, shadow_ray), 0.0f);
+    float glossy = 1.0f;
+    // IsInShadow(hitPoint, shadowRay, 0.0001f, distance), objects.cs:56
+    const int occluder = light_occluder<COUNT>(s, cell, r.hit, shadow_ray, dot3(shadow_ray, shadow_ray), distance,
+                                               r.far, r.any_far, active, tc);
+    if (occluder != INT_MAX) {
+        diffuse = 0.0f;
+        glossy = 0.0f;
     }
-    final = mk3(clamp01(final.x), clamp01(final.y), clamp01(final.z));  // objects.cs:94
-    if (!active) return;
+    const f3 diffuse_color = scale3(r.base, diffuse);
+    const f3 reflection = sub3(shadow_ray, scale3(r.normal, 2.0f * dot3(shadow_ray, r.normal)));
+    const float sp = pow250(net_maxf(dot3(reflection, r.view), 0.0f));
+    const f3 glossy_color = scale3(scale3(r.mat_glossy, sp), glossy);
+    const float d2 = distance * distance;
+    reflected = mk3(0.0f, 0.0f, 0.0f);
+    if (r.have_refl) reflected = mk3(ieee_div(r.refl_term.x, d2), ieee_div(r.refl_term.y, d2), ieee_div(r.refl_term.z, d2));
+    // light.color * 1 / (distance*distance) * (diffuseColor + glossyColor) + ambient
+    // (per component; the reference's lights are (2, 2, 2): equal components share the quotient)
+    f3 li;
+    li.x = ieee_div(lc.x * 1.0f, d2);
+    if (lc.y == lc.x && lc.z == lc.x) li.y = li.z = li.x;   // wave-uniform
+    else li.y = ieee_div(lc.y * 1.0f, d2), li.z = ieee_div(lc.z * 1.0f, d2);
+    const f3 dg = add3(diffuse_color, glossy_color);
+    direct = add3(mk3(li.x * dg.x, li.y * dg.y, li.z * dg.z), r.mat_ambient);
+}
+
+// The clamp of objects.cs:94 and where the colour goes: the pixel (level 0) or the parent record.
+__device__ __forceinline__ void shade_store(const DevFrame &f, const int level, const int parent, f3 final,
+                                            const bool through, int32_t *pixels)
+{
+    final = mk3(clamp01(final.x), clamp01(final.y), clamp01(final.z));
     if (level == 0) {
         // Primitive.MixColor objects.cs:35-41 -> Surface.pixels (MyApplication.cs:420)
         const uint32_t r = (uint32_t)net_f2i(final.x * 255.0f);
@@ -1687,6 +1713,29 @@ __device__ __forceinline__ void shade_record(const DevScene &s, const DevFrame &
     } else {
         f.refl[parent] = make_float4(final.x, final.y, final.z, 1.0f);
     }
+}
+
+// Primitive.Shade for one record per lane, the lights one after the other.
+template <bool COUNT>
+__device__ __forceinline__ void shade_record(const DevScene &s, const DevFrame &f, const int level, const int slot,
+                                             const bool active, const bool reflecting, const bool through,
+                                             int32_t *pixels, TestCount &tc)
+{
+    const ShadeRecord r = shade_setup(s, f, slot, active, reflecting, through);
+    f3 final = mk3(0.0f, 0.0f, 0.0f);
+    const int nl = s.nl;
+    // The table cell of light l + 1 is fetched while light l is shaded.
+    uint2 cell_next = make_uint2(0u, 0u);
+    if (s.lt_n > 0 && nl > 0) cell_next = light_table_cell(s, 0, sub3(r.hit, xyz(cload(s.light_pos, 0))));
+    for (int l = 0; l < nl; l++) {
+        const uint2 cell = cell_next;
+        if (s.lt_n > 0 && l + 1 < nl) cell_next = light_table_cell(s, l + 1, sub3(r.hit, xyz(cload(s.light_pos, l + 1))));
+        f3 reflected, direct;
+        light_terms<COUNT>(s, r, l, cell, active, tc, reflected, direct);
+        if (r.have_refl) final = add3(final, reflected);
+        final = add3(final, direct);
+    }
+    if (active) shade_store(f, level, r.parent, final, through, pixels);
 }
 
 // One tile = 256 consecutive records of one queue of one level, one record per lane.
@@ -1775,6 +1824,7 @@ __global__ void __launch_bounds__(256) k_reflect(DevScene s, DevFrame f, int lev
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int n = f.cnt[2 * level];
     const int ntiles = (n + 255) >> 8;
+    if (MULTI && f.split_chunks && ntiles < f.split_below) return;   // k_reflect_chunks takes this level
     if (!MULTI && (int)blockIdx.x < ntiles) {
         stage_chunk(L, s, 0, s.ns_padded);
         __syncthreads();
@@ -1782,6 +1832,173 @@ __global__ void __launch_bounds__(256) k_reflect(DevScene s, DevFrame f, int lev
     TestCount tc = {0, 0, 0, 0, 0, 0, 0};
     PhaseClock pc = {};
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) reflection_tile<MULTI>(s, f, L, blk, level, tile, n, tc, pc);
+    if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
+}
+
+// ---------------------------------------------------------------------------------------
+// Reflection rays of a scene of many chunks, one (tile, chunk) pair per job.  After the first
+// bounce the rays of a tile point everywhere, so the tile's workgroup would stage and walk nearly
+// every chunk of the scene one after the other (k_reflect: ~15 us per chunk, 64 chunks); here
+// the pairs are independent jobs spread over the device.  That pays when the level has too few
+// tiles to fill the device (below DevFrame::split_below: deep levels cost ~1 ms each whatever their
+// size, against 30-500 us as jobs); a level with more tiles keeps k_reflect, whose workgroups walk
+// their chunks nearest first and stop at the closest hit.  Both are launched for every level and
+// the one whose turn it is not returns at once.  A job tests the tile's rays against the
+// chunk's ball, and if any can meet it stages the chunk, walks it, and merges each ray's closest
+// hit into the record's refl slot with a 64-bit atomic minimum of (bits of t) << 32 | host index:
+// t > 0, so the order of the keys is the order of (t, index) that Scene.Intersect's strict `<`
+// implies (MyApplication.cs:361).  k_reflect_finish then adds planes and triangles, and pushes
+// the next level's records, as k_reflect does.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long hit_key(const float t, const int prim)
+{
+    return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned)prim;
+}
+
+// Can the ray (o, d) meet the ball {P, R} (DevScene::chk_b)?  By "Bounding balls" above the
+// forward half-line of a ray that hits a member comes within R' = R + 1.31e-3 (|o - P| + R) of P,
+// so the ray misses when o is outside and either P is behind it or farther than R' from its
+// line.  FP32 evaluation with room (1e-5 |v| on d.v, 1e-4 on R'^2); anything not finite meets.
+__device__ __forceinline__ bool ray_meets_ball(const f3 o, const f3 d, const float4 b)
+{
+    const f3 v = mk3(b.x - o.x, b.y - o.y, b.z - o.z);
+    const float D2 = __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x));
+    const float D = __builtin_amdgcn_sqrtf(D2);
+    const float R = __builtin_fmaf(1.5e-3f, D + b.w, b.w);
+    const float R2 = R * R * 1.0001f + 1e-5f * D2;
+    const float c = __builtin_fmaf(d.z, v.z, __builtin_fmaf(d.y, v.y, d.x * v.x));
+    const bool outside = D2 > R2 * 1.002f;
+    const bool miss = c < -1e-5f * D || __builtin_fmaf(-c, c, D2) > R2;
+    return !(outside && miss);
+}
+
+// The mirror direction of a record and what it starts from.
+struct ReflectionRay {
+    f3 hit, dir;
+    float a;
+    int slot;
+    bool active;
+};
+__device__ __forceinline__ ReflectionRay reflection_ray(const DevScene &s, const DevFrame &f, const int level,
+                                                        const int tile, const int n, const bool through)
+{
+    ReflectionRay r;
+    const int i = tile * 256 + threadIdx.x;
+    r.active = i < n;
+    r.slot = level * f.P + (r.active ? i : n - 1);
+    float4 ra, rb;
+    if (through) load_record(&f.recA[r.slot], &f.recB[r.slot], ra, rb);
+    else ra = f.recA[r.slot], rb = f.recB[r.slot];
+    r.hit = xyz(ra);
+    const f3 view = xyz(rb);
+    const int prim = __float_as_int(ra.w);
+    const int type = __float_as_int(cload(s.mat, 3 * prim + 1).w) & RT_MF_TYPE_MASK;
+    const f3 normal = record_normal(s, prim, type, r.hit);
+    // objects.cs:82: (viewDir - 2 * Dot(viewDir, normal) * normal).Normalized()
+    r.dir = normalized3(sub3(view, scale3(normal, 2.0f * dot3(view, normal))));
+    r.a = dot3(r.dir, r.dir);
+    return r;
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_reflect_chunks(DevScene s, DevFrame f, int level)
+{
+    __shared__ WalkLds L;
+    __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
+    const int n = f.cnt[2 * level];
+    const int ntiles = (n + 255) >> 8;
+    if (ntiles >= f.split_below) return;   // enough tiles to fill the device: k_reflect takes this level
+    const int nsp = s.ns_padded, nchk = (nsp + RT_CHUNK - 1) / RT_CHUNK;
+    const long long jobs = (long long)ntiles * (long long)nchk;
+    TestCount tc = {0, 0, 0, 0, 0, 0, 0};
+    PhaseClock pc = {};
+    const unsigned live[4] = {~0u, ~0u, ~0u, ~0u};
+    int tile_held = -1;
+    ReflectionRay r = {};
+#pragma clang loop unroll(disable)
+    for (long long job = blockIdx.x; job < jobs; job += gridDim.x) {
+        // Jobs of one tile are neighbours: chunk = job % nchk.
+        const int tile = (int)(job / nchk), chunk = (int)(job % nchk);
+        if (tile != tile_held) {
+            r = reflection_ray(s, f, level, tile, n, false);
+            tile_held = tile;
+        }
+        const float4 ball = s.chk_b[chunk];
+        const bool meets = r.active && ball.w >= 0.0f && ray_meets_ball(r.hit, r.dir, ball);
+        if (!__syncthreads_or(meets ? 1 : 0)) continue;   // (also: everybody is done with the staged chunk)
+        const int base = chunk * RT_CHUNK, cnt = min(RT_CHUNK, nsp - base);
+        stage_chunk(L, s, base, cnt);
+        __syncthreads();
+        const FilterOrigin fo = filter_origin(s, r.hit);
+        f4raw rq[4];
+        rq[0] = filter_ray(fo, r.dir);
+#pragma unroll
+        for (int l = 1; l < 4; l++) rq[l] = f4raw{0.f, 0.f, 0.f, 0.f};
+        float best_t = RT_FLT_MAX;
+        int best_prim = INT_MAX;
+        // Sphere.Intersect objects.cs:112-121, literally; equal distances: the lower host index.
+        auto exact = [&](auto, const float4 sp, const int orig) {
+            const f3 op = sub3(r.hit, xyz(sp));
+            const float c = dot3(op, op) - sp.w;
+            const float x = dot3(r.dir, op);
+            float t;
+            if (sphere_maybe(x, r.a * c) && sphere_root(x, c, r.a, t) && t > RT_EPS &&
+                (t < best_t || (t == best_t && orig < best_prim))) {
+                best_t = t;
+                best_prim = orig;
+            }
+        };
+        FilterWork fw = {0, 0, 0};
+        walk_chunk<1, true, false>(L, cnt, s.sph + base, s.sph_orig + base, rq, fo.lane_s, fo.lane_g, fo.lane, fw, pc,
+                                   exact, live);
+        if (r.active && best_prim != INT_MAX)
+            atomicMin(reinterpret_cast<unsigned long long *>(&f.refl[r.slot]), hit_key(best_t, best_prim));
+        tc.exact += r.active ? fw.candidates : 0;
+        tc.filt_terms += fw.terms;
+        tc.filt_rays += fw.ray_tests;
+    }
+    if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_reflect_finish(DevScene s, DevFrame f, int level)
+{
+    __shared__ int blk[12];
+    __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
+    const int n = f.cnt[2 * level];
+    const int ntiles = (n + 255) >> 8;
+    if (ntiles >= f.split_below) return;
+    TestCount tc = {0, 0, 0, 0, 0, 0, 0};
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const ReflectionRay r = reflection_ray(s, f, level, tile, n, false);
+        // the closest sphere, as the jobs of k_reflect_chunks left it
+        const unsigned long long key = *reinterpret_cast<const unsigned long long *>(&f.refl[r.slot]);
+        Closest sec = {RT_FLT_MAX, INT_MAX};
+        if (key != ~0ull) sec.t = __uint_as_float((unsigned)(key >> 32)), sec.prim = (int)(unsigned)key;
+        for (int j = 0; j < s.np; j++) {
+            const float4 pl = cload(s.pl, j);
+            const f3 nn = xyz(pl);
+            float t;
+            if (plane_t(nn, (-dot3(nn, r.hit)) - pl.w, r.dir, t)) closest_offer(sec, t, cload(s.pl_orig, j));
+        }
+        for (int j = 0; j < s.nt; j++) {
+            const f3 v0 = xyz(cload(s.tri, 3 * j)), e1 = xyz(cload(s.tri, 3 * j + 1)), e2 = xyz(cload(s.tri, 3 * j + 2));
+            float t;
+            if (triangle_t(e1, e2, sub3(r.hit, v0), r.dir, t)) closest_offer(sec, t, cload(s.tri_orig, j));
+        }
+        if (r.active) {
+            tc.sph += s.ns;
+            tc.pl += s.np;
+            tc.tri += s.nt;
+        }
+        const bool child = r.active && sec.prim != INT_MAX;
+        const f3 hit2 = add3(r.hit, scale3(r.dir, sec.t));   // objects.cs:123,166,263
+        if (r.active) f.refl[r.slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // no reflected colour yet
+        const bool rv[1] = {child};
+        const int rp[1] = {child ? sec.prim : 0}, rparent[1] = {r.slot};
+        const f3 rh[1] = {hit2}, rd[1] = {r.dir};
+        push_records<1, false>(f, s, level + 1, blk, rv, rp, rh, rd, rparent);
+    }
     if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
 }
 
@@ -1794,6 +2011,7 @@ k_plain(DevScene s, DevFrame f, int level, int32_t *pixels)
 {
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int n = f.cnt[2 * level + 1];
+    if (f.light_waves > 0 && n < f.light_split_below) return;   // k_shade_lights takes this queue
     const int ntiles = (n + 255) >> 8;
     TestCount tc = {0, 0, 0, 0, 0, 0, 0};
     PhaseClock pc = {};
@@ -2009,6 +2227,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
 {
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int na = f.cnt[2 * level];
+    if (f.light_waves > 0 && na < f.light_split_below) return;   // k_shade_lights takes this queue
     const int stride = gridDim.x * blockDim.x;
     TestCount tc = {0, 0, 0, 0, 0, 0, 0};
     // (whole waves: the light rays of a record are traced by its wave together)
@@ -2016,6 +2235,63 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
         const int i = i0 + threadIdx.x;
         const bool active = i < na;
         shade_record<COUNT>(s, f, level, level * f.P + (active ? i : na - 1), active, true, false, pixels, tc);
+    }
+    if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
+}
+
+// ---------------------------------------------------------------------------------------
+// Shading with the lights spread over the waves of a workgroup, for queues too short to fill the
+// device with one record per lane: a lone wave issues an instruction only every ~4.5 cycles, and
+// a record's light loop is one dependent chain of ~400 instructions per light, so a level of a few
+// thousand records takes as long as its longest chain (16 lights: ~200 us) however few they are.
+// Here a workgroup takes 64 records; wave w computes what lights w, w + W, ... add to the colour
+// (light_terms: the same arithmetic as shade_record), the addends meet in LDS, and wave 0 adds them
+// in the reference's order, so the sum is the same float for float.  Launched beside k_plain
+// (reflecting = 0) and k_shade (reflecting = 1); whichever of the two forms the queue's length
+// does not call for returns at once (DevFrame::light_waves, light_split_below).
+// ---------------------------------------------------------------------------------------
+#define LIGHT_WAVES_MAX 16
+template <bool COUNT>
+__global__ void __launch_bounds__(64 * LIGHT_WAVES_MAX) k_shade_lights(DevScene s, DevFrame f, int level, int reflecting,
+                                                                      int32_t *pixels)
+{
+    __shared__ float terms[LIGHT_WAVES_MAX][6][64];
+    __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
+    const int n = f.cnt[2 * level + (reflecting ? 0 : 1)];
+    if (!(n < f.light_split_below)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+    const int ntiles = (n + 63) >> 6;
+    const int nl = s.nl;
+    TestCount tc = {0, 0, 0, 0, 0, 0, 0};
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int i = tile * 64 + lane;
+        const bool active = i < n;
+        const int ii = active ? i : n - 1;
+        const int slot = reflecting ? level * f.P + ii : (level + 1) * f.P - 1 - ii;
+        const bool through = !reflecting;   // as k_plain and k_shade read and write their records
+        const ShadeRecord r = shade_setup(s, f, slot, active, reflecting != 0, through);
+        f3 final = mk3(0.0f, 0.0f, 0.0f);
+        for (int l0 = 0; l0 < nl; l0 += W) {
+            const int l = l0 + wave;
+            if (l < nl) {
+                uint2 cell = make_uint2(0u, 0u);
+                if (s.lt_n > 0) cell = light_table_cell(s, l, sub3(r.hit, xyz(cload(s.light_pos, l))));
+                f3 reflected, direct;
+                light_terms<COUNT>(s, r, l, cell, active, tc, reflected, direct);
+                terms[wave][0][lane] = reflected.x, terms[wave][1][lane] = reflected.y, terms[wave][2][lane] = reflected.z;
+                terms[wave][3][lane] = direct.x, terms[wave][4][lane] = direct.y, terms[wave][5][lane] = direct.z;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const int m = min(W, nl - l0);
+                for (int w = 0; w < m; w++) {
+                    if (r.have_refl) final = add3(final, mk3(terms[w][0][lane], terms[w][1][lane], terms[w][2][lane]));
+                    final = add3(final, mk3(terms[w][3][lane], terms[w][4][lane], terms[w][5][lane]));
+                }
+            }
+            __syncthreads();
+        }
+        if (wave == 0 && active) shade_store(f, level, r.parent, final, through, pixels);
     }
     if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
 }
@@ -2196,6 +2472,18 @@ void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting,
     }
 }
 
+void rtk_reflect_chunks(const DevScene &s, const DevFrame &f, int level, int job_blocks, int tile_blocks, hipStream_t stream)
+{
+    const dim3 b(256);
+    if (f.any_hit == 0) {
+        hipLaunchKernelGGL(k_reflect_chunks<true>, dim3(job_blocks), b, 0, stream, s, f, level);
+        hipLaunchKernelGGL(k_reflect_finish<true>, dim3(tile_blocks), b, 0, stream, s, f, level);
+    } else {
+        hipLaunchKernelGGL(k_reflect_chunks<false>, dim3(job_blocks), b, 0, stream, s, f, level);
+        hipLaunchKernelGGL(k_reflect_finish<false>, dim3(tile_blocks), b, 0, stream, s, f, level);
+    }
+}
+
 typedef void (*trace_levels_kernel)(DevScene, DevFrame, int32_t *);
 template <bool RESERVE, bool COUNT>
 static trace_levels_kernel trace_levels_pick(const DevScene &s)
@@ -2223,6 +2511,14 @@ void rtk_trace_levels(const DevScene &s, const DevFrame &f, int32_t *pixels, int
 {
     hipLaunchKernelGGL(trace_levels_for(s, f.chain_policy != 0, f.any_hit == 0), dim3(grid_blocks), dim3(256), 0, stream, s, f,
                        pixels);
+}
+
+void rtk_shade_lights(const DevScene &s, const DevFrame &f, int level, bool reflecting, int32_t *pixels, int grid_blocks,
+                      hipStream_t stream)
+{
+    const dim3 g(grid_blocks), b(64 * f.light_waves);
+    if (f.any_hit == 0) hipLaunchKernelGGL(k_shade_lights<true>, g, b, 0, stream, s, f, level, reflecting ? 1 : 0, pixels);
+    else hipLaunchKernelGGL(k_shade_lights<false>, g, b, 0, stream, s, f, level, reflecting ? 1 : 0, pixels);
 }
 
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
