@@ -16,9 +16,10 @@ Printed by rank 0: one JSON line with
                step ends with the frame in rank 0's DEVICE memory
   roofline     the levels stage, i.e. everything between the primary-ray kernel and the final
                shading passes: one k_reflect launch per level (the reflection rays' closest-hit
-               walks, on a second stream) beside one k_plain launch per level (light rays and
-               shading of the records that reflect nothing), or on small frames one
-               k_trace_levels launch that does both.  The FLOP the stage EXECUTED per frame
+               walks, on a second stream; k_reflect_chunks + k_reflect_finish for small levels of
+               many-chunk scenes) beside one k_plain launch per level (light rays and shading of the
+               records that reflect nothing; k_shade_lights for short queues of many-light scenes),
+               or on small frames one k_trace_levels launch that does both.  The FLOP the stage EXECUTED per frame
                (filter evaluations of rays against spheres and bounding balls, per-origin terms,
                exact Intersect of the candidates and of the spheres the lights' direction tables
                list, plane and triangle tests; from the library's work counters) / its HIP-event
@@ -293,8 +294,9 @@ def main() -> None:
                 "timed_step_ends": "frame in device memory of rank 0 (see handoff for the host copy)",
             },
             "roofline": {
-                "bound": "valu-fp32", "kernel": "levels stage of a frame: k_reflect per level (reflection rays) on a second stream beside "
-                                                 "k_plain per level (light rays + shading of plain records); 'launch' = one frame's stage",
+                "bound": "valu-fp32", "kernel": "levels stage of a frame: k_reflect (or k_reflect_chunks + k_reflect_finish) per level (reflection "
+                                                 "rays) on a second stream beside k_plain (or k_shade_lights) per level (light rays + shading "
+                                                 "of plain records); 'launch' = one frame's stage",
                 "achieved": round(executed, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(executed / PEAK_FP32_TFLOPS, 4),
                 "executed_flop_per_launch": executed_flop / world,

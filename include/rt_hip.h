@@ -246,6 +246,11 @@ int rt_unpin_pixels(rt_ctx *ctx);
  * a non-blocking stream the context owns, which nothing else is ordered against: pass the
  * stream the consumer of the pixels runs on) and the call returns without synchronising; per-frame
  * scratch is owned by the context, so calls on one context must not overlap.
+ * Device memory: every render entry keeps the frame's ray queues in the context, sized for the
+ * worst case (every pixel alive at every level) and grown, never shrunk, when a larger frame
+ * comes: 48 bytes * pixels of the call (rounded up to 64) * (max_depth + 1), i.e. 2.0 GB for
+ * 3840x2160 at max_depth 4 and 14.3 GB for 7680x4320 at max_depth 8; RT_ERR_OUT_OF_MEMORY when
+ * the device cannot give that.  A rank of a row partition allocates for its own rows only.
  * This is the per-rank entry of the one-process-per-GPU row partition: rank r of
  * G renders its block and the framebuffer blocks are gathered with one
  * collective.  It is also Render() for hosts that present straight from device

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-frame figures of the levels stage (the launches between k_primary and the first k_shade of a
-frame: k_reflect and k_plain per level, or one k_trace_levels) from rocprofv3 output.
+frame: k_reflect / k_reflect_chunks / k_reflect_finish and k_plain / k_shade_lights per level, or one
+k_trace_levels) from rocprofv3 output.  (k_shade_lights also runs beside k_shade after the stage; its
+launches there are counted with the stage's sums but do not stretch the stage's span.)
 
   stage_profile.py span results.db [frames]
       kernel-trace database (rocpd sqlite): per frame the wall span of the stage (first launch's
@@ -18,7 +20,7 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-STAGE = ("k_reflect", "k_plain", "k_trace_levels")
+STAGE = ("k_reflect", "k_plain", "k_trace_levels", "k_shade_lights")
 
 
 def short(name: str) -> str:
@@ -44,7 +46,8 @@ def span(path: str, frames: int) -> None:
         per_frame = per_frame[:frames]
     stage_span, frame_span, sums = [], [], defaultdict(list)
     for fr in per_frame:
-        st = [(k, s, e) for k, s, e in fr if k.startswith(STAGE)]
+        first_shade = min([s for k, s, e in fr if k.startswith("k_shade<")], default=None)
+        st = [(k, s, e) for k, s, e in fr if k.startswith(STAGE) and (first_shade is None or s < first_shade)]
         if not st:
             continue
         stage_span.append(max(e for _, _, e in st) - min(s for _, s, _ in st))
@@ -66,19 +69,25 @@ def span(path: str, frames: int) -> None:
 
 
 def pmc(out: str, passes) -> None:
-    result = {"kernels": "k_reflect + k_plain (+ k_trace_levels) launches of a frame", "per": "frame"}
+    result = {"kernels": "the launches of a frame between k_primary and the first k_shade: k_reflect / k_reflect_chunks / "
+                         "k_reflect_finish, k_plain / k_shade_lights (or k_trace_levels)", "per": "frame"}
     for spec in passes:
         label, path = spec.split("=", 1)
         acc, frames = defaultdict(float), set()
         per_kernel = defaultdict(lambda: defaultdict(float))
         with open(path) as f:
-            for row in csv.DictReader(f):
-                k = short(row["Kernel_Name"])
-                if k.startswith("k_primary"):
-                    frames.add(row["Dispatch_Id"])
-                if k.startswith(STAGE):
-                    acc[row["Counter_Name"]] += float(row["Counter_Value"])
-                    per_kernel[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            rows = sorted(csv.DictReader(f), key=lambda row: int(row["Dispatch_Id"]))
+        in_stage = False   # between a frame's k_primary and its first k_shade
+        for row in rows:
+            k = short(row["Kernel_Name"])
+            if k.startswith("k_primary"):
+                frames.add(row["Dispatch_Id"])
+                in_stage = True
+            elif k.startswith("k_shade<"):
+                in_stage = False
+            if in_stage and k.startswith(STAGE):
+                acc[row["Counter_Name"]] += float(row["Counter_Value"])
+                per_kernel[k][row["Counter_Name"]] += float(row["Counter_Value"])
         n = max(1, len(frames))
         result.setdefault("frames_profiled", {})[label] = n
         for c, v in acc.items():
