@@ -1093,13 +1093,15 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // Scenes of several chunks, one launch per level: the reflection rays of a level are traced as
     // (tile, chunk) jobs (k_reflect_chunks).  RT_HIP_SPLIT_CHUNKS=0 (tuning aid) keeps a tile's chunks
     // to its own workgroup.
-    static const bool split_env = !getenv("RT_HIP_SPLIT_CHUNKS") || atoi(getenv("RT_HIP_SPLIT_CHUNKS")) != 0;
+    const char *split_chunks_env = getenv("RT_HIP_SPLIT_CHUNKS"), *split_below_str = getenv("RT_HIP_SPLIT_BELOW");
+    const bool split_env = !split_chunks_env || atoi(split_chunks_env) != 0;
     fr.split_chunks = !fused && split_env && d.scene.ns_padded > RT_CHUNK ? 1 : 0;
-    static const int split_below_env = getenv("RT_HIP_SPLIT_BELOW") ? atoi(getenv("RT_HIP_SPLIT_BELOW")) : 0;
+    const int split_below_env = split_below_str ? atoi(split_below_str) : 0;
     fr.split_below = split_below_env > 0 ? split_below_env : std::max(1, d.num_cus * 2 / share);
     // Scenes with several lights, one launch per level: short queues are shaded with the lights spread
     // over the waves of a workgroup (k_shade_lights).  RT_HIP_LIGHT_SPLIT_BELOW=n (tuning aid; 0 = never).
-    static const int light_below_env = getenv("RT_HIP_LIGHT_SPLIT_BELOW") ? atoi(getenv("RT_HIP_LIGHT_SPLIT_BELOW")) : -1;
+    const char *light_below_str = getenv("RT_HIP_LIGHT_SPLIT_BELOW");   // (these knobs are read at every call)
+    const int light_below_env = light_below_str ? atoi(light_below_str) : -1;
     const int nl = d.scene.nl;
     fr.light_waves = fused || nl < 3 || light_below_env == 0 ? 0 : nl >= 12 ? 16 : nl >= 6 ? 8 : 4;
     fr.light_split_below = light_below_env > 0 ? light_below_env : 64 * 1024 / share;

@@ -181,3 +181,48 @@ def test_thin_frames_over_64k_spheres(ctx, oracle):
     fs = scene_64k().flatten()
     for (w, h) in [(1, 96), (96, 1), (3, 67)]:
         exact(ctx, oracle, fs, Camera(), w, h, 8, f"64k spheres {w}x{h}")
+
+
+@pytest.mark.parametrize("pipeline", ["levels", "fused"])
+def test_both_forms_of_the_levels_stage(oracle, monkeypatch, pipeline):
+    """Small frames normally take the single-launch form of the levels' work; large ones one launch
+    per level and queue, where many-chunk scenes trace small levels as (tile, chunk) jobs and
+    many-light scenes shade short queues with the lights spread over waves.  Both forms forced on
+    the scenes that reach those paths, with the work counters on and off: same pixels, same counts."""
+    monkeypatch.setenv("RT_HIP_PIPELINE", pipeline)
+    with RenderContext() as c:
+        for profiling in (1, 0):
+            c.set_profiling(profiling)
+            fs = scene_64k().flatten()                      # 64 chunks, 16 lights, 8 levels
+            exact(c, oracle, fs, Camera(), 80, 45, 8, f"64k spheres, {pipeline}", counters=profiling == 1)
+            s = synthetic_scene(300, radius=(0.05, 0.3), seed=5)   # one chunk, 5 and then 33 lights
+            s.lights.clear()
+            for i in range(5):
+                s.Add(Light(-2.0 + i, -3.0 + 0.3 * i, 0.5 + 0.4 * i))
+            exact(c, oracle, s, Camera(), 96, 64, 4, f"5 lights, {pipeline}", counters=profiling == 1)
+            for i in range(28):
+                s.Add(Light(-3.0 + 0.2 * i, -2.5, 0.4 + 0.1 * i))
+            exact(c, oracle, s, Camera(position=(0.2, -0.1, 0.0)), 64, 48, 3, f"33 lights, {pipeline}",
+                  counters=profiling == 1)
+
+
+def test_chunk_jobs_and_tile_walks_agree_on_a_large_frame(oracle, monkeypatch):
+    """The 64-chunk scene on a frame large enough for one launch per level by itself: level 0 has
+    enough tiles for the tile-serial walk, deeper levels become (tile, chunk) jobs; with the switch
+    forced either way every level takes one form.  All three frames are identical, and every 40th
+    row equals the CPU restatement."""
+    fs = scene_64k().flatten()
+    w, h, depth = 640, 360, 6
+    frames = []
+    monkeypatch.setenv("RT_HIP_PIPELINE", "levels")
+    with RenderContext() as c:
+        c.set_scene(fs)
+        for below in ("", "1", "1000000"):
+            if below:
+                monkeypatch.setenv("RT_HIP_SPLIT_BELOW", below)
+            frames.append(c.render(Camera(), w, h, depth))
+            c.frame_status()
+    assert np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[2])
+    ref, _ = oracle.render(fs, Camera(), w, h, max_depth=depth, row_step=40)
+    rows = list(range(0, h, 40))
+    assert np.array_equal(frames[0][rows], ref[rows])
