@@ -336,6 +336,32 @@ def main() -> None:
                 ctx.unpin_pixels()
             except RtError as e:
                 pinned = f"refused ({e.message.split(';')[0]})"
+            # The same frames with two in flight, each in a render context of its own (a host that
+            # presents from device memory can enqueue frame i + 1 before frame i is done): the idle
+            # stretches of one frame's chain of levels are filled by the other's kernels.
+            second = RenderContext([dev_index])
+            second.set_scene(flat)
+            pair = [ctx, second]
+            for c in pair:
+                c.set_device_share(2)
+            two = FramePipeline(W, H, rank, world, device, depth=2, contexts=pair)
+            reps2 = max(10, args.steps // 2)
+            for _ in range(4):
+                two.render_frame(None, cam, DEPTH)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(reps2):
+                two.render_frame(None, cam, DEPTH)
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t2) / reps2 * 1e3
+            for c in pair:
+                c.frame_status()
+                c.set_device_share(1)
+            second.close()
+            line["pipelined"] = {"frames_in_flight": 2, "ms_per_frame": round(ms2, 4),
+                                 "Mrays_per_s": round(rays / (ms2 * 1e-3) / 1e6, 2),
+                                 "note": "not `value`: two render contexts on the one GPU, frames enqueued back to back "
+                                         "without waiting; `value` is one frame at a time, what a blocking Render() sees"}
             handoff = {"rt_render_pageable_ms": round(pageable, 4), "rt_render_pinned_ms": pinned,
                        "note": "whole rt_render calls (kernels + copy into the caller's int[w*h]); a frame this size is "
                                "rendered in row blocks whose copies overlap the next block's kernels"}
