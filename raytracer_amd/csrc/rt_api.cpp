@@ -919,6 +919,8 @@ int place_fixed_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth)
     DevFrame &f = d.fixed;
     f.counters = reinterpret_cast<DevCounters *>(p);
     f.sched = reinterpret_cast<DevSched *>(p + RT_COUNTER_SLOTS * sizeof(DevCounters));
+    static_assert((RT_COUNTER_SLOTS * sizeof(DevCounters) + sizeof(DevSched)) % 8 == 0,
+                  "a level's two record counts are updated as one aligned 64-bit word (push_records)");
     f.cnt = reinterpret_cast<int *>(p + RT_COUNTER_SLOTS * sizeof(DevCounters) + sizeof(DevSched));
     p += FRAME_CONTROL_BYTES;
     f.recA = reinterpret_cast<float4 *>(p);

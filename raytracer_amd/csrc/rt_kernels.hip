@@ -267,8 +267,14 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
             ta += a;
             tb += b;
         }
-        blk[8] = ta ? atomicAdd(&f.cnt[2 * level], ta) : 0;
-        blk[9] = tb ? atomicAdd(&f.cnt[2 * level + 1], tb) : 0;
+        // Both queues' counters in ONE returning atomic (they are the two halves of an aligned
+        // 64-bit word; neither half can carry: a level holds fewer than 2^31 records).
+        unsigned long long before = 0ull;
+        if (ta | tb)
+            before = atomicAdd(reinterpret_cast<unsigned long long *>(&f.cnt[2 * level]),
+                               ((unsigned long long)(unsigned)tb << 32) | (unsigned long long)(unsigned)ta);
+        blk[8] = (int)(unsigned)before;
+        blk[9] = (int)(unsigned)(before >> 32);
     }
     __syncthreads();
     const int base_a = blk[8] + blk[2 * wave], base_b = blk[9] + blk[2 * wave + 1];
