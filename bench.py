@@ -108,8 +108,8 @@ def pmc_summary(name: str) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -345,7 +345,7 @@ def main() -> None:
             for c in pair:
                 c.set_device_share(2)
             two = FramePipeline(W, H, rank, world, device, depth=2, contexts=pair)
-            reps2 = max(10, args.steps // 2)
+            reps2 = max(10, min(200, args.steps // 2))
             for _ in range(4):
                 two.render_frame(None, cam, DEPTH)
             torch.cuda.synchronize()

@@ -109,6 +109,11 @@ struct DeviceState {
     DevFrame &last() { return last_fixed ? fixed : frame; }
     unsigned char *scratch_base = nullptr;   // this device's copy of the fixed scratch array
     size_t cap_slots = 0;
+    // Buffers of the record binning (k_bin_*), sized for one level of the largest frame so far.
+    uint2 *bin_aux = nullptr;
+    float4 *bin_tmp_a = nullptr, *bin_tmp_b = nullptr;
+    int *bin_hist = nullptr;   // histograms, then the prefix sums: 4 * RT_BINS ints
+    size_t cap_bin = 0;
     int32_t *out = nullptr;  // device framebuffer block of this device
     size_t cap_out = 0;
     int32_t *bands = nullptr;  // this device's bands of an interleaved partition, stacked (rt_render, several devices)
@@ -238,6 +243,14 @@ void free_frame(DeviceState &d)
     if (d.frame.recB) (void)hipFree(d.frame.recB);
     if (d.frame.refl) (void)hipFree(d.frame.refl);
     if (d.frame.counters) (void)hipFree(d.frame.counters);   // counters, sched and cnt are one allocation
+    if (d.bin_aux) (void)hipFree(d.bin_aux);
+    if (d.bin_tmp_a) (void)hipFree(d.bin_tmp_a);
+    if (d.bin_tmp_b) (void)hipFree(d.bin_tmp_b);
+    if (d.bin_hist) (void)hipFree(d.bin_hist);
+    d.bin_aux = nullptr;
+    d.bin_tmp_a = d.bin_tmp_b = nullptr;
+    d.bin_hist = nullptr;
+    d.cap_bin = 0;
     if (d.out) (void)hipFree(d.out);
     d.frame = DevFrame{};
     d.out = nullptr;
@@ -265,6 +278,7 @@ struct PackedScene {
     uint32_t textures_used = 0;
     float sph_center[3] = {0.f, 0.f, 0.f};
     float sph_l1max = 0.f, sph_sc = 0.f, grp_rmax = 0.f, sup_rmax = 0.f, chk_rmax = 0.f;
+    float bin_lo[3] = {0.f, 0.f, 0.f}, bin_scale[3] = {0.f, 0.f, 0.f};   // position bins (DevScene)
     // Per-light direction tables (build_light_tables).
     std::vector<uint2> lt_cells;
     std::vector<float4> lt_sph;
@@ -340,6 +354,14 @@ void build_filter_arrays(PackedScene &out)
     for (int k = 0; k < 3; k++) {
         out.sph_center[k] = lo[k] <= hi[k] ? (float)(0.5 * (lo[k] + hi[k])) : 0.f;
         cen[k] = out.sph_center[k];
+    }
+    // Position bins over the extent of the centres (a degenerate or unrepresentable extent: one bin).
+    for (int k = 0; k < 3; k++) {
+        const double width = hi[k] - lo[k];
+        const float scale = width > 0.0 ? (float)((double)RT_BIN_AXIS / width) : 0.f;
+        out.bin_lo[k] = lo[k] <= hi[k] ? (float)lo[k] : 0.f;
+        out.bin_scale[k] = std::isfinite(scale) && std::isfinite(out.bin_lo[k]) ? scale : 0.f;
+        if (!std::isfinite(out.bin_lo[k])) out.bin_lo[k] = 0.f;
     }
     const float4 never = make_float4(0.f, 0.f, 0.f, -INFINITY);
     out.sph_f.assign(n, never);
@@ -821,6 +843,7 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     sc.chk_rmax = ps.chk_rmax;
     for (int k = 0; k < 3; k++) sc.sph_center[k] = ps.sph_center[k];
     sc.sph_l1max = ps.sph_l1max;
+    for (int k = 0; k < 3; k++) sc.bin_lo[k] = ps.bin_lo[k], sc.bin_scale[k] = ps.bin_scale[k];
     sc.sph_sc = ps.sph_sc;
     return RT_OK;
 }
@@ -1107,6 +1130,38 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     const int nl = d.scene.nl;
     fr.light_waves = fused || nl < 3 || light_below_env == 0 ? 0 : nl >= 12 ? 16 : nl >= 6 ? 8 : 4;
     fr.light_split_below = light_below_env > 0 ? light_below_env : 64 * 1024 / share;
+    // Scenes of several chunks or many lights, one launch per level: the records of a level >= 1 are put
+    // into the order of their hit points' position bins before the level is used (k_bin_*).
+    // RT_HIP_BIN_MIN=n (tuning aid): for levels of at least n records; 0 = never.
+    const char *bin_min_str = getenv("RT_HIP_BIN_MIN");
+    const int bin_min_env = bin_min_str ? atoi(bin_min_str) : -1;
+    fr.bin_min = 0;
+    if (!fused && !fixed_scratch && max_depth > 0 && bin_min_env != 0 && (d.scene.ns_padded > RT_CHUNK || nl >= 8) &&
+        d.scene.bin_scale[0] > 0.f) {
+        const size_t stride = (size_t)fr.P;
+        if (stride > d.cap_bin) {
+            if (d.bin_aux) (void)hipFree(d.bin_aux);
+            if (d.bin_tmp_a) (void)hipFree(d.bin_tmp_a);
+            if (d.bin_tmp_b) (void)hipFree(d.bin_tmp_b);
+            d.bin_aux = nullptr;
+            d.bin_tmp_a = d.bin_tmp_b = nullptr;
+            d.cap_bin = 0;
+            HIP_TRY(ctx, hipMalloc((void **)&d.bin_aux, stride * sizeof(uint2)));
+            HIP_TRY(ctx, hipMalloc((void **)&d.bin_tmp_a, stride * sizeof(float4)));
+            HIP_TRY(ctx, hipMalloc((void **)&d.bin_tmp_b, stride * sizeof(float4)));
+            d.cap_bin = stride;
+        }
+        if (!d.bin_hist) {
+            HIP_TRY(ctx, hipMalloc((void **)&d.bin_hist, 4 * RT_BINS * sizeof(int)));
+            HIP_TRY(ctx, hipMemsetAsync(d.bin_hist, 0, 4 * RT_BINS * sizeof(int), stream));   // (the kernels zero it after use)
+        }
+        fr.bin_min = bin_min_env > 0 ? bin_min_env : 16384;
+        fr.bin_aux = d.bin_aux;
+        fr.bin_tmp_a = d.bin_tmp_a;
+        fr.bin_tmp_b = d.bin_tmp_b;
+        fr.bin_hist = d.bin_hist;
+        fr.bin_base = d.bin_hist + 2 * RT_BINS;
+    }
     d.last_stream = stream;
     const DevFrame &f = fr;
     if (part > 0) HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, FRAME_CONTROL_BYTES - RT_COUNTER_SLOTS * sizeof(DevCounters), stream));
@@ -1144,6 +1199,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
             if (k < max_depth) {
                 rtk_trace(d.scene, f, k, true, dev_pixels, blocks, chain);
                 if (f.split_chunks) rtk_reflect_chunks(d.scene, f, k, std::max(1, d.num_cus * 4 / share), blocks, chain);
+                if (f.bin_min > 0) rtk_bin_level(d.scene, f, k + 1, std::max(1, d.num_cus * 8 / share), chain);
                 if (two_streams) HIP_TRY(ctx, hipEventRecord(d.ev_level[k], d.aux));
             }
             if (two_streams && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(stream, d.ev_level[k - 1], 0));

@@ -91,6 +91,9 @@ struct DevScene {
                               // (widened) sphere; a cell's entries are sorted by it
     int lt_n;
     float lt_near;
+    // Position bins (k_bin_*): cell of a point = floor((p - bin_lo) * bin_scale) per axis, clamped to
+    // 0 .. RT_BIN_AXIS - 1; the box is the spheres' extent.  bin_scale[0] = 0: no box.
+    float bin_lo[3], bin_scale[3];
     const uchar4 *tex[RT_DEV_MAX_TEXTURES];
     int tex_w[RT_DEV_MAX_TEXTURES];
     int tex_h[RT_DEV_MAX_TEXTURES];
@@ -162,6 +165,8 @@ struct DevSched {
 //                                         the pixel index at level 0 (int bits)
 //   refl[slot] = {rgb of the reflected Shade(), valid}   written by the child
 #define RT_LEVEL_ALIGN 64
+#define RT_BIN_AXIS 16                                         // position bins per axis
+#define RT_BINS (RT_BIN_AXIS * RT_BIN_AXIS * RT_BIN_AXIS)      // per queue
 struct DevFrame {
     float4 *recA;
     float4 *recB;
@@ -182,6 +187,14 @@ struct DevFrame {
     int *status;
     unsigned stall_ticks;  // how long a workgroup waits without progress, in ticks of the 100 MHz wall clock
     int debug_withhold;    // test knob: the first reflecting tile of this level is never counted as done (-1: off)
+    // Records of a level >= 1 put into the order of their hit points' position bins before the level is
+    // traced and shaded (k_bin_*): bin_min > 0 enables it for levels of at least that many records.
+    int bin_min;
+    uint2 *bin_aux;        // per record of the level being binned: {bin, rank within the bin}
+    float4 *bin_tmp_a;     // the level's records in their new order, before they are copied back
+    float4 *bin_tmp_b;
+    int *bin_hist;         // [2 * RT_BINS] records per bin (reflecting queue, plain queue); zero between uses
+    int *bin_base;         // [2 * RT_BINS] first position of each bin in its queue
     int light_waves;       // > 0: queues of fewer than light_split_below records are shaded with the lights spread
     int light_split_below; // over that many waves per 64 records (k_shade_lights)
     int split_chunks;      // 1: levels with fewer than split_below reflecting tiles are traced one (tile, chunk)
@@ -198,6 +211,8 @@ void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting,
 // The reflecting records of a level of a many-chunk scene as (tile, chunk) jobs, then the pass that
 // completes them (planes, triangles, next level's records).  Needs DevFrame::split_chunks.
 void rtk_reflect_chunks(const DevScene &s, const DevFrame &f, int level, int job_blocks, int tile_blocks, hipStream_t stream);
+// The records of level `level` reordered by position bin (four launches; see DevFrame::bin_min).
+void rtk_bin_level(const DevScene &s, const DevFrame &f, int level, int grid_blocks, hipStream_t stream);
 // Every level in one launch; grid_blocks = workgroups resident at once on the device
 // (rtk_trace_levels_resident_blocks), fewer if the frame has fewer tiles.
 // (of the instance rtk_trace_levels launches for a frame with that chain policy / counting mode)

@@ -186,10 +186,12 @@ def test_thin_frames_over_64k_spheres(ctx, oracle):
 @pytest.mark.parametrize("pipeline", ["levels", "fused"])
 def test_both_forms_of_the_levels_stage(oracle, monkeypatch, pipeline):
     """Small frames normally take the single-launch form of the levels' work; large ones one launch
-    per level and queue, where many-chunk scenes trace small levels as (tile, chunk) jobs and
-    many-light scenes shade short queues with the lights spread over waves.  Both forms forced on
+    per level and queue, where many-chunk scenes trace small levels as (tile, chunk) jobs,
+    many-light scenes shade short queues with the lights spread over waves, and both reorder the
+    records of deeper levels by position.  Both forms forced on
     the scenes that reach those paths, with the work counters on and off: same pixels, same counts."""
     monkeypatch.setenv("RT_HIP_PIPELINE", pipeline)
+    monkeypatch.setenv("RT_HIP_BIN_MIN", "64")   # (levels: even these small levels are put into bin order)
     with RenderContext() as c:
         for profiling in (1, 0):
             c.set_profiling(profiling)
