@@ -83,8 +83,8 @@ struct DeviceState {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {};  // begin, after primary, after trace, after shade, after gather copy
-    // Frames rendered as one launch per level and queue: the reflecting records' launches run on a
-    // second stream beside the plain records' (enqueue_rows), ordered by these events.
+    // Frames rendered as one launch per level and queue: the plain records' launches run on a
+    // second stream beside the reflecting records' (enqueue_rows), ordered by these events.
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_level[RT_MAX_DEPTH + 1] = {};
     int num_cus = 256;
@@ -1177,10 +1177,10 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
                 std::min((tiles32 >= 16 * d.num_cus ? d.num_cus * 4 : d.num_cus * 8) / share, RT_COUNTER_SLOTS), stream);
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[1], stream));
     // Two forms of the levels' work.  "levels": one launch per level and queue; the reflecting
-    // records' launches (the chain: level k + 1 exists when level k's are done) go to a second
+    // records' launches (the chain: level k + 1 exists when level k's are done) stay on the caller's
     // stream, the plain records' launches (shaded on the spot, no successors, most of the work, in
-    // a kernel of their own that needs few registers and runs at twice the occupancy) stay on the
-    // caller's stream and fill the device beside them.  "fused": every level in ONE launch of
+    // a kernel of their own that needs few registers and runs at a higher occupancy) go to a second
+    // stream and fill the device beside them.  "fused": every level in ONE launch of
     // resident workgroups with a device-side schedule (k_trace_levels): no launch gaps between the
     // levels of a small frame, but plain records then run at the walk kernel's occupancy.
     // RT_HIP_PIPELINE=levels|fused (tuning aid) overrides; RT_HIP_LEVEL_KERNELS=1 (profiling aid)
@@ -1190,21 +1190,29 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
         const bool two_streams = !level_kernels && !counting && max_depth > 0;
         const int plain_blocks = std::max(1, std::min({tiles0, d.num_cus * 16 / share, RT_COUNTER_SLOTS}));
         const int light_blocks = std::max(1, std::min(d.num_cus * 8 / share, RT_COUNTER_SLOTS));
-        hipStream_t chain = two_streams ? d.aux : stream;
+        // The chain stays on the caller's stream (a dependency between two launches of one stream costs
+        // ~6 us, across streams ~12, and the chain is the frame's critical path); the plain records'
+        // launches go to the second stream, except the deepest level's, which the chain ends with.
+        hipStream_t side = two_streams ? d.aux : stream;
         if (two_streams) {
             HIP_TRY(ctx, hipEventRecord(d.ev_fork, stream));
             HIP_TRY(ctx, hipStreamWaitEvent(d.aux, d.ev_fork, 0));
         }
         for (int k = 0; k <= max_depth; k++) {
             if (k < max_depth) {
-                rtk_trace(d.scene, f, k, true, dev_pixels, blocks, chain);
-                if (f.split_chunks) rtk_reflect_chunks(d.scene, f, k, std::max(1, d.num_cus * 4 / share), blocks, chain);
-                if (f.bin_min > 0) rtk_bin_level(d.scene, f, k + 1, std::max(1, d.num_cus * 8 / share), chain);
-                if (two_streams) HIP_TRY(ctx, hipEventRecord(d.ev_level[k], d.aux));
+                rtk_trace(d.scene, f, k, true, dev_pixels, blocks, stream);
+                if (f.split_chunks) rtk_reflect_chunks(d.scene, f, k, std::max(1, d.num_cus * 4 / share), blocks, stream);
+                if (f.bin_min > 0) rtk_bin_level(d.scene, f, k + 1, std::max(1, d.num_cus * 8 / share), stream);
+                if (two_streams) HIP_TRY(ctx, hipEventRecord(d.ev_level[k], stream));
             }
-            if (two_streams && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(stream, d.ev_level[k - 1], 0));
-            rtk_trace(d.scene, f, k, false, dev_pixels, plain_blocks, stream);
-            if (f.light_waves) rtk_shade_lights(d.scene, f, k, false, dev_pixels, light_blocks, stream);
+            hipStream_t where = k == max_depth ? stream : side;
+            if (two_streams && k > 0 && k < max_depth) HIP_TRY(ctx, hipStreamWaitEvent(d.aux, d.ev_level[k - 1], 0));
+            rtk_trace(d.scene, f, k, false, dev_pixels, plain_blocks, where);
+            if (f.light_waves) rtk_shade_lights(d.scene, f, k, false, dev_pixels, light_blocks, where);
+        }
+        if (two_streams) {   // the reflecting records' shading below needs every plain level
+            HIP_TRY(ctx, hipEventRecord(d.ev_fork, d.aux));
+            HIP_TRY(ctx, hipStreamWaitEvent(stream, d.ev_fork, 0));
         }
     } else {
         // Every level in one launch of resident workgroups (k_trace_levels).
