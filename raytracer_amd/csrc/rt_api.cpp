@@ -78,6 +78,7 @@ thread_local char g_create_error[RT_ERROR_CHARS] = "";
 // milliseconds (RT_HIP_STALL_MS overrides): far above anything a healthy frame shows (levels open
 // every few tens of microseconds), short enough that a lost frame is reported at once.
 constexpr unsigned RT_STALL_MS_DEFAULT = 1000;
+constexpr size_t RT_LIT_MAX_BYTES = (size_t)16 << 30;
 
 struct DeviceState {
     int device = 0;
@@ -87,6 +88,7 @@ struct DeviceState {
     // second stream beside the reflecting records' (enqueue_rows), ordered by these events.
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_level[RT_MAX_DEPTH + 1] = {};
+
     int num_cus = 256;
     // k_trace_levels workgroups resident at once, per instance [chain policy][counting] (0: ask
     // again, the scene changed)
@@ -114,6 +116,9 @@ struct DeviceState {
     float4 *bin_tmp_a = nullptr, *bin_tmp_b = nullptr;
     int *bin_hist = nullptr;   // histograms, then the prefix sums: 4 * RT_BINS ints
     size_t cap_bin = 0;
+    // Light terms of the reflecting records (DevFrame::lit), for cap_lit float4s.
+    float4 *lit = nullptr;
+    size_t cap_lit = 0;
     int32_t *out = nullptr;  // device framebuffer block of this device
     size_t cap_out = 0;
     int32_t *bands = nullptr;  // this device's bands of an interleaved partition, stacked (rt_render, several devices)
@@ -251,6 +256,9 @@ void free_frame(DeviceState &d)
     d.bin_tmp_a = d.bin_tmp_b = nullptr;
     d.bin_hist = nullptr;
     d.cap_bin = 0;
+    if (d.lit) (void)hipFree(d.lit);
+    d.lit = nullptr;
+    d.cap_lit = 0;
     if (d.out) (void)hipFree(d.out);
     d.frame = DevFrame{};
     d.out = nullptr;
@@ -1162,6 +1170,29 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
         fr.bin_hist = d.bin_hist;
         fr.bin_base = d.bin_hist + 2 * RT_BINS;
     }
+    // Scenes with few lights, one launch per level: the reflecting records' light terms are computed
+    // beside the plain records' shading (k_lit), so that the passes at the end of the frame, which
+    // nothing can overlap, only add them up.  Costs 16 bytes per slot of the levels below max_depth and
+    // light; not beyond RT_LIT_MAX_BYTES.  RT_HIP_EARLY_LIGHTS=0 (tuning aid) turns it off.
+    fr.lit = nullptr;
+    {
+        const char *early_env = getenv("RT_HIP_EARLY_LIGHTS");
+        const size_t want = (size_t)fr.P * (size_t)max_depth * (size_t)std::max(nl, 1);
+        // (not for a context that shares its device with others rendering at the same time: there the
+        // tail of one frame is filled by the other frames' kernels anyway, and the extra traffic costs 5 %)
+        if (!fused && !fixed_scratch && share == 1 && max_depth > 0 && nl >= 1 && nl <= 4 &&
+            (!early_env || atoi(early_env) != 0) &&
+            want * sizeof(float4) <= RT_LIT_MAX_BYTES) {
+            if (want > d.cap_lit) {
+                if (d.lit) (void)hipFree(d.lit);
+                d.lit = nullptr;
+                d.cap_lit = 0;
+                HIP_TRY(ctx, hipMalloc((void **)&d.lit, want * sizeof(float4)));
+                d.cap_lit = want;
+            }
+            fr.lit = d.lit;
+        }
+    }
     d.last_stream = stream;
     const DevFrame &f = fr;
     if (part > 0) HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, FRAME_CONTROL_BYTES - RT_COUNTER_SLOTS * sizeof(DevCounters), stream));
@@ -1209,8 +1240,9 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
             if (two_streams && k > 0 && k < max_depth) HIP_TRY(ctx, hipStreamWaitEvent(d.aux, d.ev_level[k - 1], 0));
             rtk_trace(d.scene, f, k, false, dev_pixels, plain_blocks, where);
             if (f.light_waves) rtk_shade_lights(d.scene, f, k, false, dev_pixels, light_blocks, where);
+            if (f.lit && k < max_depth) rtk_lit_level(d.scene, f, k, plain_blocks, where);
         }
-        if (two_streams) {   // the reflecting records' shading below needs every plain level
+        if (two_streams) {   // the reflecting records' shading below needs every plain level (and the light terms)
             HIP_TRY(ctx, hipEventRecord(d.ev_fork, d.aux));
             HIP_TRY(ctx, hipStreamWaitEvent(stream, d.ev_fork, 0));
         }
@@ -1225,7 +1257,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // (the reflecting records; the deepest level has none)
     for (int k = max_depth - 1; k >= 0; k--) {
         rtk_shade_level(d.scene, f, k, dev_pixels, std::min(shade_blocks, RT_COUNTER_SLOTS), stream);
-        if (f.light_waves)
+        if (f.light_waves && !f.lit)
             rtk_shade_lights(d.scene, f, k, true, dev_pixels, std::max(1, std::min(d.num_cus * 8 / share, RT_COUNTER_SLOTS)), stream);
     }
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[3], stream));

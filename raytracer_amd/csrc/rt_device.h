@@ -195,6 +195,10 @@ struct DevFrame {
     float4 *bin_tmp_b;
     int *bin_hist;         // [2 * RT_BINS] records per bin (reflecting queue, plain queue); zero between uses
     int *bin_base;         // [2 * RT_BINS] first position of each bin in its queue
+    // Light terms of the reflecting records, computed ahead of their children (k_lit): per slot of the
+    // levels below max_depth and per light {what the light adds directly (rgb), distance * distance}.
+    // Null: k_shade runs the whole light loop itself.
+    float4 *lit;
     int light_waves;       // > 0: queues of fewer than light_split_below records are shaded with the lights spread
     int light_split_below; // over that many waves per 64 records (k_shade_lights)
     int split_chunks;      // 1: levels with fewer than split_below reflecting tiles are traced one (tile, chunk)
@@ -220,6 +224,8 @@ int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus, bool reserv
 void rtk_trace_levels(const DevScene &s, const DevFrame &f, int32_t *pixels, int grid_blocks, hipStream_t stream);
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
                      int grid_blocks, hipStream_t stream);
+// The light terms of a level's reflecting records into DevFrame::lit (which must not be null).
+void rtk_lit_level(const DevScene &s, const DevFrame &f, int level, int grid_blocks, hipStream_t stream);
 // The plain (reflecting = false) or reflecting records of a level, lights spread over DevFrame::light_waves
 // waves per 64 records; does nothing unless the queue is shorter than DevFrame::light_split_below.
 void rtk_shade_lights(const DevScene &s, const DevFrame &f, int level, bool reflecting, int32_t *pixels, int grid_blocks,

@@ -1669,9 +1669,10 @@ __device__ __forceinline__ ShadeRecord shade_setup(const DevScene &s, const DevF
 // One pass of the reference's light loop (objects.cs:51-91) for light l: what it adds to finalColor,
 // in its order: first `reflected` (only when the record has a reflected colour), then `direct`.
 // cell: the light's table cell for this origin (light_table_cell).  Every lane of the wave must call it.
+// d2: distance * distance, the divisor of the reflected colour (for callers that add it later).
 template <bool COUNT>
 __device__ __forceinline__ void light_terms(const DevScene &s, const ShadeRecord &r, const int l, const uint2 cell,
-                                            const bool active, TestCount &tc, f3 &reflected, f3 &direct)
+                                            const bool active, TestCount &tc, f3 &reflected, f3 &direct, float &d2)
 {
     const f3 lp = xyz(cload(s.light_pos, l)), lc = xyz(cload(s.light_col, l));
     const f3 to_light = sub3(lp, r.hit);
@@ -1690,7 +1691,7 @@ __device__ __forceinline__ void light_terms(const DevScene &s, const ShadeRecord
     const f3 reflection = sub3(shadow_ray, scale3(r.normal, 2.0f * dot3(shadow_ray, r.normal)));
     const float sp = pow250(net_maxf(dot3(reflection, r.view), 0.0f));
     const f3 glossy_color = scale3(scale3(r.mat_glossy, sp), glossy);
-    const float d2 = distance * distance;
+    d2 = distance * distance;
     reflected = mk3(0.0f, 0.0f, 0.0f);
     if (r.have_refl) reflected = mk3(ieee_div(r.refl_term.x, d2), ieee_div(r.refl_term.y, d2), ieee_div(r.refl_term.z, d2));
     // light.color * 1 / (distance*distance) * (diffuseColor + glossyColor) + ambient
@@ -1737,11 +1738,54 @@ __device__ __forceinline__ void shade_record(const DevScene &s, const DevFrame &
         const uint2 cell = cell_next;
         if (s.lt_n > 0 && l + 1 < nl) cell_next = light_table_cell(s, l + 1, sub3(r.hit, xyz(cload(s.light_pos, l + 1))));
         f3 reflected, direct;
-        light_terms<COUNT>(s, r, l, cell, active, tc, reflected, direct);
+        float d2;
+        light_terms<COUNT>(s, r, l, cell, active, tc, reflected, direct, d2);
         if (r.have_refl) final = add3(final, reflected);
         final = add3(final, direct);
     }
     if (active) shade_store(f, level, r.parent, final, through, pixels);
+}
+
+// A reflecting record's light loop does not depend on its child: what every light adds directly, and
+// the divisor of the reflected colour, are computed as soon as the record exists (lit_record / k_lit,
+// beside the plain records' shading, while the chain of reflection levels is the frame's critical
+// path) and kept in DevFrame::lit; once the child's colour is there only the sum is left
+// (combine_record): the same additions in the same order as shade_record makes them.  Every lane of
+// the wave must call lit_record.
+template <bool COUNT>
+__device__ __forceinline__ void lit_record(const DevScene &s, const DevFrame &f, const int slot, const bool active,
+                                           TestCount &tc)
+{
+    const ShadeRecord r = shade_setup(s, f, slot, active, false, false);
+    const int nl = s.nl;
+    uint2 cell_next = make_uint2(0u, 0u);
+    if (s.lt_n > 0 && nl > 0) cell_next = light_table_cell(s, 0, sub3(r.hit, xyz(cload(s.light_pos, 0))));
+    for (int l = 0; l < nl; l++) {
+        const uint2 cell = cell_next;
+        if (s.lt_n > 0 && l + 1 < nl) cell_next = light_table_cell(s, l + 1, sub3(r.hit, xyz(cload(s.light_pos, l + 1))));
+        f3 reflected, direct;
+        float d2;
+        light_terms<COUNT>(s, r, l, cell, active, tc, reflected, direct, d2);
+        if (active) f.lit[(size_t)slot * (size_t)nl + (size_t)l] = make_float4(direct.x, direct.y, direct.z, d2);
+    }
+}
+
+__device__ __forceinline__ void combine_record(const DevScene &s, const DevFrame &f, const int level, const int slot,
+                                               int32_t *pixels)
+{
+    const int prim = __float_as_int(f.recA[slot].w), parent = __float_as_int(f.recB[slot].w);
+    const float specular = cload(s.mat, 3 * prim).w;
+    const float4 rf = f.refl[slot];
+    const bool have_refl = rf.w != 0.0f;
+    const f3 refl_term = scale3(scale3(xyz(rf), specular), 1.0f);   // (Vector4)Shade(..) * material.specular * 1
+    f3 final = mk3(0.0f, 0.0f, 0.0f);
+    const int nl = s.nl;
+    for (int l = 0; l < nl; l++) {
+        const float4 t = f.lit[(size_t)slot * (size_t)nl + (size_t)l];
+        if (have_refl) final = add3(final, mk3(ieee_div(refl_term.x, t.w), ieee_div(refl_term.y, t.w), ieee_div(refl_term.z, t.w)));
+        final = add3(final, xyz(t));
+    }
+    shade_store(f, level, parent, final, false, pixels);
 }
 
 // One tile = 256 consecutive records of one queue of one level, one record per lane.
@@ -2161,6 +2205,22 @@ k_plain(DevScene s, DevFrame f, int level, int32_t *pixels)
     if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
 }
 
+// The light terms of a level's reflecting records (lit_record), one record per lane.
+template <bool COUNT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_PLAIN_WAVES)))
+k_lit(DevScene s, DevFrame f, int level)
+{
+    __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
+    const int n = f.cnt[2 * level];
+    const int ntiles = (n + 255) >> 8;
+    TestCount tc = {0, 0, 0, 0, 0, 0, 0};
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int i = tile * 256 + threadIdx.x;
+        lit_record<COUNT>(s, f, level * f.P + (i < n ? i : n - 1), i < n, tc);
+    }
+    if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
+}
+
 // ---------------------------------------------------------------------------------------
 // trace_levels: every level of the frame in ONE launch of resident workgroups that take
 // tiles from a shared schedule (DevSched).  Level k+1's records exist once all reflecting
@@ -2369,6 +2429,11 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
 {
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int na = f.cnt[2 * level];
+    if (f.lit) {   // the light terms are there (k_lit): only the sums are left
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na; i += gridDim.x * blockDim.x)
+            combine_record(s, f, level, level * f.P + i, pixels);
+        return;
+    }
     if (f.light_waves > 0 && na < f.light_split_below) return;   // k_shade_lights takes this queue
     const int stride = gridDim.x * blockDim.x;
     TestCount tc = {0, 0, 0, 0, 0, 0, 0};
@@ -2419,7 +2484,8 @@ __global__ void __launch_bounds__(64 * LIGHT_WAVES_MAX) k_shade_lights(DevScene 
                 uint2 cell = make_uint2(0u, 0u);
                 if (s.lt_n > 0) cell = light_table_cell(s, l, sub3(r.hit, xyz(cload(s.light_pos, l))));
                 f3 reflected, direct;
-                light_terms<COUNT>(s, r, l, cell, active, tc, reflected, direct);
+                float d2;
+                light_terms<COUNT>(s, r, l, cell, active, tc, reflected, direct, d2);
                 terms[wave][0][lane] = reflected.x, terms[wave][1][lane] = reflected.y, terms[wave][2][lane] = reflected.z;
                 terms[wave][3][lane] = direct.x, terms[wave][4][lane] = direct.y, terms[wave][5][lane] = direct.z;
             }
@@ -2662,6 +2728,12 @@ void rtk_trace_levels(const DevScene &s, const DevFrame &f, int32_t *pixels, int
 {
     hipLaunchKernelGGL(trace_levels_for(s, f.chain_policy != 0, f.any_hit == 0), dim3(grid_blocks), dim3(256), 0, stream, s, f,
                        pixels);
+}
+
+void rtk_lit_level(const DevScene &s, const DevFrame &f, int level, int grid_blocks, hipStream_t stream)
+{
+    if (f.any_hit == 0) hipLaunchKernelGGL(k_lit<true>, dim3(grid_blocks), dim3(256), 0, stream, s, f, level);
+    else hipLaunchKernelGGL(k_lit<false>, dim3(grid_blocks), dim3(256), 0, stream, s, f, level);
 }
 
 void rtk_shade_lights(const DevScene &s, const DevFrame &f, int level, bool reflecting, int32_t *pixels, int grid_blocks,

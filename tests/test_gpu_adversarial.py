@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from raytracer_amd import (Camera, Light, Material, Plane, RenderContext, Scene, Sphere, Triangle,
-                           default_scene, scene_64k, synthetic_scene)
+                           default_scene, scene_1k, scene_64k, synthetic_scene)
 
 pytestmark = pytest.mark.gpu
 
@@ -197,6 +197,8 @@ def test_both_forms_of_the_levels_stage(oracle, monkeypatch, pipeline):
             c.set_profiling(profiling)
             fs = scene_64k().flatten()                      # 64 chunks, 16 lights, 8 levels
             exact(c, oracle, fs, Camera(), 80, 45, 8, f"64k spheres, {pipeline}", counters=profiling == 1)
+            # two lights: the reflecting records' light terms are computed ahead of their children
+            exact(c, oracle, scene_1k().flatten(), Camera(), 128, 72, 4, f"1k spheres, {pipeline}", counters=profiling == 1)
             s = synthetic_scene(300, radius=(0.05, 0.3), seed=5)   # one chunk, 5 and then 33 lights
             s.lights.clear()
             for i in range(5):
