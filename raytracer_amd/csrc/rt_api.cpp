@@ -1238,6 +1238,19 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
             }
             hipStream_t where = k == max_depth ? stream : side;
             if (two_streams && k > 0 && k < max_depth) HIP_TRY(ctx, hipStreamWaitEvent(d.aux, d.ev_level[k - 1], 0));
+            // The two levels below the deepest are small: one launch for both (and their light terms),
+            // issued when the second one's records exist; every launch of its own would add its start-up
+            // to the second stream, which would then end after the chain.
+            const bool tail_pair = two_streams && max_depth >= 3;
+            if (tail_pair && k == max_depth - 2) continue;
+            if (tail_pair && k == max_depth - 1) {
+                rtk_plain_levels(d.scene, f, k - 1, k, dev_pixels, plain_blocks, where);
+                if (f.light_waves) {
+                    rtk_shade_lights(d.scene, f, k - 1, false, dev_pixels, light_blocks, where);
+                    rtk_shade_lights(d.scene, f, k, false, dev_pixels, light_blocks, where);
+                }
+                continue;
+            }
             rtk_trace(d.scene, f, k, false, dev_pixels, plain_blocks, where);
             if (f.light_waves) rtk_shade_lights(d.scene, f, k, false, dev_pixels, light_blocks, where);
             if (f.lit && k < max_depth) rtk_lit_level(d.scene, f, k, plain_blocks, where);

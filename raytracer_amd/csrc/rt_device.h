@@ -224,6 +224,10 @@ int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus, bool reserv
 void rtk_trace_levels(const DevScene &s, const DevFrame &f, int32_t *pixels, int grid_blocks, hipStream_t stream);
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
                      int grid_blocks, hipStream_t stream);
+// The plain records of levels level_lo .. level_hi in one launch, with the light terms of their reflecting
+// records when DevFrame::lit is set.
+void rtk_plain_levels(const DevScene &s, const DevFrame &f, int level_lo, int level_hi, int32_t *pixels, int grid_blocks,
+                      hipStream_t stream);
 // The light terms of a level's reflecting records into DevFrame::lit (which must not be null).
 void rtk_lit_level(const DevScene &s, const DevFrame &f, int level, int grid_blocks, hipStream_t stream);
 // The plain (reflecting = false) or reflecting records of a level, lights spread over DevFrame::light_waves

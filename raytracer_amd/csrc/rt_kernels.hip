@@ -2205,6 +2205,35 @@ k_plain(DevScene s, DevFrame f, int level, int32_t *pixels)
     if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
 }
 
+// The last small levels of a frame in ONE launch (levels level .. level_hi: their plain records, and
+// their reflecting records' light terms when DevFrame::lit is set): a launch of its own for each
+// would cost more in start-up than in work.  (A kernel of its own, so that k_plain keeps its
+// registers.)
+template <bool COUNT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_PLAIN_WAVES)))
+k_plain_tail(DevScene s, DevFrame f, int level, int level_hi, int32_t *pixels)
+{
+    __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
+    TestCount tc = {0, 0, 0, 0, 0, 0, 0};
+    PhaseClock pc = {};
+    for (int lv = level; lv <= level_hi; lv++) {
+        const int n = f.cnt[2 * lv + 1];
+        if (!(f.light_waves > 0 && n < f.light_split_below)) {   // (else k_shade_lights takes this queue)
+            const int ntiles = (n + 255) >> 8;
+            for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) plain_tile<COUNT>(s, f, lv, tile, n, pixels, tc, pc);
+        }
+        if (f.lit && lv < f.max_depth) {
+            const int na = f.cnt[2 * lv];
+            const int ntiles = (na + 255) >> 8;
+            for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+                const int i = tile * 256 + threadIdx.x;
+                lit_record<COUNT>(s, f, lv * f.P + (i < na ? i : na - 1), i < na, tc);
+            }
+        }
+    }
+    if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
+}
+
 // The light terms of a level's reflecting records (lit_record), one record per lane.
 template <bool COUNT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_PLAIN_WAVES)))
@@ -2728,6 +2757,14 @@ void rtk_trace_levels(const DevScene &s, const DevFrame &f, int32_t *pixels, int
 {
     hipLaunchKernelGGL(trace_levels_for(s, f.chain_policy != 0, f.any_hit == 0), dim3(grid_blocks), dim3(256), 0, stream, s, f,
                        pixels);
+}
+
+void rtk_plain_levels(const DevScene &s, const DevFrame &f, int level_lo, int level_hi, int32_t *pixels, int grid_blocks,
+                      hipStream_t stream)
+{
+    const dim3 g(grid_blocks), b(256);
+    if (f.any_hit == 0) hipLaunchKernelGGL(k_plain_tail<true>, g, b, 0, stream, s, f, level_lo, level_hi, pixels);
+    else hipLaunchKernelGGL(k_plain_tail<false>, g, b, 0, stream, s, f, level_lo, level_hi, pixels);
 }
 
 void rtk_lit_level(const DevScene &s, const DevFrame &f, int level, int grid_blocks, hipStream_t stream)
