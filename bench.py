@@ -143,8 +143,9 @@ def main() -> None:
     # One GPU: one frame at a time (what the C# host's blocking Render() sees, and the condition
     # the kernel durations below are measured under).  Several ranks: frames in flight, each in a
     # render context of its own, so that a frame's gather (and rank 0's row permutation) and the
-    # idle stretches of its chain of reflection levels are filled by the next frames' kernels.
-    in_flight = int(os.environ.get("RT_BENCH_FRAMES_IN_FLIGHT", "0")) or (1 if world == 1 else 3 if world >= 8 else 2)
+    # idle stretches of its chain of reflection levels are filled by the next frames' kernels (four:
+    # measured on one MI355X with a rank's share of the frame, profiles/r02_pipeline_sweep.txt).
+    in_flight = int(os.environ.get("RT_BENCH_FRAMES_IN_FLIGHT", "0")) or (1 if world == 1 else 4)
     contexts = [RenderContext([dev_index]) for _ in range(in_flight)]
     for c in contexts:
         c.set_scene(flat)

@@ -136,13 +136,13 @@ def main():
                               "efficiency_if_no_gather": round(full_ms / (G * max(ms)), 4)}), flush=True)
     if "pipe" in want:
         # Frames in flight: part 0 of G interleaved parts of the frame (what one rank of G renders),
-        # rendered back to back by 1, 2, 3 contexts taking turns, each on a stream of its own and
+        # rendered back to back by 1 .. 8 contexts taking turns, each on a stream of its own and
         # sized for its share of the device.  ms per frame = wall time / frames.
         flat = scene_1k().flatten()
         (w, h), depth = (int(v) for v in args.split_size.split("x")), 4
         for G in (8, 4, 2, 1):
             rows = (h + G - 1) // G + 16
-            for n_ctx, share in ((1, 1), (2, 1), (2, 2), (3, 3), (4, 4)):
+            for n_ctx, share in ((1, 1), (2, 2), (3, 3), (4, 4), (6, 6), (8, 8), (6, 4), (8, 4)):
                 ctxs = [RenderContext([0]) for _ in range(n_ctx)]
                 streams = [torch.cuda.Stream() for _ in range(n_ctx)]
                 bufs = [torch.empty((rows, w), dtype=torch.int32, device="cuda") for _ in range(n_ctx)]
