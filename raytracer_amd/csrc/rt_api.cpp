@@ -115,10 +115,10 @@ struct DeviceState {
     uint2 *bin_aux = nullptr;
     float4 *bin_tmp_a = nullptr, *bin_tmp_b = nullptr;
     int *bin_hist = nullptr;   // histograms, then the prefix sums: 4 * RT_BINS ints
-    size_t cap_bin = 0;
+    size_t cap_bin = 0, bin_refused = SIZE_MAX;
     // Light terms of the reflecting records (DevFrame::lit), for cap_lit float4s.
     float4 *lit = nullptr;
-    size_t cap_lit = 0;
+    size_t cap_lit = 0, lit_refused = SIZE_MAX;   // (lit_refused: the smallest size the device could not give)
     int32_t *out = nullptr;  // device framebuffer block of this device
     size_t cap_out = 0;
     int32_t *bands = nullptr;  // this device's bands of an interleaved partition, stacked (rt_render, several devices)
@@ -1147,28 +1147,44 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     if (!fused && !fixed_scratch && max_depth > 0 && bin_min_env != 0 && (d.scene.ns_padded > RT_CHUNK || nl >= 8) &&
         d.scene.bin_scale[0] > 0.f) {
         const size_t stride = (size_t)fr.P;
-        if (stride > d.cap_bin) {
+        if (stride > d.cap_bin && stride < d.bin_refused) {
             if (d.bin_aux) (void)hipFree(d.bin_aux);
             if (d.bin_tmp_a) (void)hipFree(d.bin_tmp_a);
             if (d.bin_tmp_b) (void)hipFree(d.bin_tmp_b);
             d.bin_aux = nullptr;
             d.bin_tmp_a = d.bin_tmp_b = nullptr;
             d.cap_bin = 0;
-            HIP_TRY(ctx, hipMalloc((void **)&d.bin_aux, stride * sizeof(uint2)));
-            HIP_TRY(ctx, hipMalloc((void **)&d.bin_tmp_a, stride * sizeof(float4)));
-            HIP_TRY(ctx, hipMalloc((void **)&d.bin_tmp_b, stride * sizeof(float4)));
-            d.cap_bin = stride;
+            // An optimisation only: a device that cannot give the memory renders without it.
+            if (hipMalloc((void **)&d.bin_aux, stride * sizeof(uint2)) == hipSuccess &&
+                hipMalloc((void **)&d.bin_tmp_a, stride * sizeof(float4)) == hipSuccess &&
+                hipMalloc((void **)&d.bin_tmp_b, stride * sizeof(float4)) == hipSuccess)
+                d.cap_bin = stride;
+            else {
+                (void)hipGetLastError();
+                if (d.bin_aux) (void)hipFree(d.bin_aux);
+                if (d.bin_tmp_a) (void)hipFree(d.bin_tmp_a);
+                if (d.bin_tmp_b) (void)hipFree(d.bin_tmp_b);
+                d.bin_aux = nullptr;
+                d.bin_tmp_a = d.bin_tmp_b = nullptr;
+                d.bin_refused = stride;
+            }
         }
-        if (!d.bin_hist) {
-            HIP_TRY(ctx, hipMalloc((void **)&d.bin_hist, 4 * RT_BINS * sizeof(int)));
-            HIP_TRY(ctx, hipMemsetAsync(d.bin_hist, 0, 4 * RT_BINS * sizeof(int), stream));   // (the kernels zero it after use)
+        if (!d.bin_hist && stride <= d.cap_bin) {
+            if (hipMalloc((void **)&d.bin_hist, 4 * RT_BINS * sizeof(int)) == hipSuccess)
+                HIP_TRY(ctx, hipMemsetAsync(d.bin_hist, 0, 4 * RT_BINS * sizeof(int), stream));   // (the kernels zero it after use)
+            else {
+                (void)hipGetLastError();
+                d.bin_hist = nullptr;
+            }
         }
-        fr.bin_min = bin_min_env > 0 ? bin_min_env : 16384;
-        fr.bin_aux = d.bin_aux;
-        fr.bin_tmp_a = d.bin_tmp_a;
-        fr.bin_tmp_b = d.bin_tmp_b;
-        fr.bin_hist = d.bin_hist;
-        fr.bin_base = d.bin_hist + 2 * RT_BINS;
+        if (stride <= d.cap_bin && d.bin_hist) {
+            fr.bin_min = bin_min_env > 0 ? bin_min_env : 16384;
+            fr.bin_aux = d.bin_aux;
+            fr.bin_tmp_a = d.bin_tmp_a;
+            fr.bin_tmp_b = d.bin_tmp_b;
+            fr.bin_hist = d.bin_hist;
+            fr.bin_base = d.bin_hist + 2 * RT_BINS;
+        }
     }
     // Scenes with few lights, one launch per level: the reflecting records' light terms are computed
     // beside the plain records' shading (k_lit), so that the passes at the end of the frame, which
@@ -1183,14 +1199,19 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
         if (!fused && !fixed_scratch && share == 1 && max_depth > 0 && nl >= 1 && nl <= 4 &&
             (!early_env || atoi(early_env) != 0) &&
             want * sizeof(float4) <= RT_LIT_MAX_BYTES) {
-            if (want > d.cap_lit) {
+            if (want > d.cap_lit && want < d.lit_refused) {
                 if (d.lit) (void)hipFree(d.lit);
                 d.lit = nullptr;
                 d.cap_lit = 0;
-                HIP_TRY(ctx, hipMalloc((void **)&d.lit, want * sizeof(float4)));
-                d.cap_lit = want;
+                // An optimisation only: a device that cannot give the memory renders without it.
+                if (hipMalloc((void **)&d.lit, want * sizeof(float4)) == hipSuccess) d.cap_lit = want;
+                else {
+                    (void)hipGetLastError();
+                    d.lit = nullptr;
+                    d.lit_refused = want;
+                }
             }
-            fr.lit = d.lit;
+            if (want <= d.cap_lit) fr.lit = d.lit;
         }
     }
     d.last_stream = stream;

@@ -796,31 +796,58 @@ __device__ __forceinline__ void walk_chunk(WalkLds &L, const int cnt, const floa
     }
 }
 
-// Can a ray from the origin whose filter operands are fo still find, inside the ball {P', W}
-// (DevScene::chk_f form: W = R*R - k1*|P'|^2), a hit at t <= best_t?  Every point of the ball is at
-// least |o - P| - R from the origin, the ray's direction has unit length to within 6 ulp, and the
-// t the reference computes for a sphere it accepts is off the geometric one by far less than the
-// slack the ball tests already allow (FILTER_BALL_SLACK times the coordinates' magnitude).
-// Anything not finite answers yes.
-__device__ __forceinline__ bool ball_within_reach(const DevScene &s, const FilterOrigin &fo, const float4 ball,
-                                                  const float best_t)
+// Can the ray (o, d) meet the ball {P, R} (DevScene::chk_b)?  By "Bounding balls" above the
+// forward half-line of a ray that hits a member comes within R' = R + 1.31e-3 (|o - P| + R) of P,
+// so the ray misses when o is outside and either P is behind it or farther than R' from its
+// line.  FP32 evaluation with room (1e-5 |v| on d.v, 1e-4 on R'^2); anything not finite meets.
+__device__ __forceinline__ bool ray_meets_ball(const f3 o, const f3 d, const float4 b)
 {
-    const float dx = fo.oc.x - ball.x, dy = fo.oc.y - ball.y, dz = fo.oc.z - ball.z;
-    const float dist = sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
-    const float pp = __builtin_fmaf(ball.z, ball.z, __builtin_fmaf(ball.y, ball.y, ball.x * ball.x));
-    const float radius = sqrtf(fmaxf(ball.w + pp, 0.0f)) * 1.00001f;
-    const float slack = FILTER_BALL_SLACK * (((fabsf(fo.oc.x) + fabsf(fo.oc.y)) + fabsf(fo.oc.z)) + s.sph_l1max);
-    const float t_low = (dist - radius) * 0.9999f - slack;
-    return !(best_t < t_low);
+    const f3 v = mk3(b.x - o.x, b.y - o.y, b.z - o.z);
+    const float D2 = __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x));
+    const float D = __builtin_amdgcn_sqrtf(D2);
+    const float R = __builtin_fmaf(1.5e-3f, D + b.w, b.w);
+    const float R2 = R * R * 1.0001f + 1e-5f * D2;
+    const float c = __builtin_fmaf(d.z, v.z, __builtin_fmaf(d.y, v.y, d.x * v.x));
+    const bool outside = D2 > R2 * 1.002f;
+    const bool miss = c < -1e-5f * D || __builtin_fmaf(-c, c, D2) > R2;
+    return !(outside && miss);
+}
+
+// ... and do so at a distance of at most `reach` (every point of the widened ball is at least
+// |o - P| - R' from o; the hit the reference computes lies within it)?
+__device__ __forceinline__ bool ray_reaches_ball(const f3 o, const f3 d, const float4 b, const float reach)
+{
+    const f3 v = mk3(b.x - o.x, b.y - o.y, b.z - o.z);
+    const float D = __builtin_amdgcn_sqrtf(__builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
+    const float R = __builtin_fmaf(1.5e-3f, D + b.w, b.w);
+    return !((D - R) * 0.999f > reach) && ray_meets_ball(o, d, b);
+}
+
+// Can the ray still gain from chunk `chunk`, given a hit at distance best_t: does it reach the
+// chunk's ball and, inside it, the ball of any of its runs of RT_SUPER spheres?  Asked before a
+// workgroup stages and walks a chunk: the chunks' balls overlap their neighbours' by far (1024
+// spheres in a cube give a ball of nearly the cube's diagonal), so a ray "meets" many chunks it
+// has no business in, and a visit costs 30-40 us.
+__device__ __forceinline__ bool chunk_may_hit(const DevScene &s, const int chunk, const f3 o, const f3 d,
+                                              const float best_t)
+{
+    const float4 cb = cload(s.chk_b, chunk);
+    if (!(cb.w >= 0.0f) || !ray_reaches_ball(o, d, cb, best_t)) return false;
+    const int nsup = s.ns_padded / RT_SUPER, s0 = chunk * (RT_CHUNK / RT_SUPER);
+    const int s1 = min(s0 + RT_CHUNK / RT_SUPER, nsup);
+    for (int si = s0; si < s1; si++) {
+        const float4 sb = cload(s.sup_b, si);
+        if (sb.w >= 0.0f && ray_reaches_ball(o, d, sb, best_t)) return true;
+    }
+    return false;
 }
 
 // The chunks of a scene with more than one: `visit(base, cnt)` is called, by the whole
 // workgroup, for every chunk whose ball some ray of some wave may hit (the chunks' balls are
 // tested GRP_CHUNK at a time with a GROUP loop, and the waves' pass bits are ORed in LDS because
 // staging a chunk is the workgroup's business).  Every thread of the workgroup must call it.
-// need(ball) (per lane; ball = the chunk's {P', W} as in DevScene::chk_f): can this lane still gain
-// from the chunk?  A chunk nobody needs any more (every ray of the workgroup has a hit closer than
-// the chunk's ball) is neither staged nor walked.
+// need(chunk) (per lane): can this lane still gain from the chunk?  A chunk nobody needs (any more)
+// is neither staged nor walked.
 template <int K, bool TRACE, bool SPLIT, class Need, class Visit>
 __device__ __forceinline__ void for_each_chunk(WalkLds &L, const DevScene &s, const f4raw (&rq)[4], const f4raw lane_c,
                                                const f3 oc, FilterWork &fw, const unsigned (&live)[4], Need &&need,
@@ -888,7 +915,7 @@ __device__ __forceinline__ void for_each_chunk(WalkLds &L, const DevScene &s, co
         for (int i = 0; i < count; i++) {
             const int chunk = first + __builtin_amdgcn_readfirstlane(L.order[i]);   // workgroup-uniform
             const int base = chunk * SPH_CHUNK;
-            if (!__syncthreads_or(need(cload(s.chk_f, chunk)) ? 1 : 0)) continue;
+            if (!__syncthreads_or(need(chunk) ? 1 : 0)) continue;
             visit(base, min(SPH_CHUNK, nsp - base));
         }
     }
@@ -1280,7 +1307,7 @@ __device__ __forceinline__ void traverse(const DevScene &s, WalkLds &L,
             walk_chunk<NR, true, SPLIT>(L, nsp, s.sph, s.sph_orig, rq, fo.lane_s, fo.lane_g, fo.lane, fw, pc, exact, live);
     } else {
         for_each_chunk<NR, true, SPLIT>(L, s, rq, fo.lane_c, fo.oc, fw, live,
-                                        [&](const float4 ball) { return !SEC || LC > 0 || ball_within_reach(s, fo, ball, best_t); },
+                                        [&](const int chunk) { return !SEC || LC > 0 || chunk_may_hit(s, chunk, o, r.sec_d, best_t); },
                                         [&](const int base, const int cnt) {
             __syncthreads();
             stage_chunk(L, s, base, cnt);
@@ -1905,23 +1932,6 @@ __device__ __forceinline__ unsigned long long hit_key(const float t, const int p
     return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned)prim;
 }
 
-// Can the ray (o, d) meet the ball {P, R} (DevScene::chk_b)?  By "Bounding balls" above the
-// forward half-line of a ray that hits a member comes within R' = R + 1.31e-3 (|o - P| + R) of P,
-// so the ray misses when o is outside and either P is behind it or farther than R' from its
-// line.  FP32 evaluation with room (1e-5 |v| on d.v, 1e-4 on R'^2); anything not finite meets.
-__device__ __forceinline__ bool ray_meets_ball(const f3 o, const f3 d, const float4 b)
-{
-    const f3 v = mk3(b.x - o.x, b.y - o.y, b.z - o.z);
-    const float D2 = __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x));
-    const float D = __builtin_amdgcn_sqrtf(D2);
-    const float R = __builtin_fmaf(1.5e-3f, D + b.w, b.w);
-    const float R2 = R * R * 1.0001f + 1e-5f * D2;
-    const float c = __builtin_fmaf(d.z, v.z, __builtin_fmaf(d.y, v.y, d.x * v.x));
-    const bool outside = D2 > R2 * 1.002f;
-    const bool miss = c < -1e-5f * D || __builtin_fmaf(-c, c, D2) > R2;
-    return !(outside && miss);
-}
-
 // The mirror direction of a record and what it starts from.
 struct ReflectionRay {
     f3 hit, dir;
@@ -1973,8 +1983,10 @@ __global__ void __launch_bounds__(256) k_reflect_chunks(DevScene s, DevFrame f, 
             r = reflection_ray(s, f, level, tile, n, false);
             tile_held = tile;
         }
-        const float4 ball = s.chk_b[chunk];
-        const bool meets = r.active && ball.w >= 0.0f && ray_meets_ball(r.hit, r.dir, ball);
+        // (the closest hit other jobs have merged so far: a plain load may see an older, farther one)
+        const unsigned long long seen = *reinterpret_cast<const unsigned long long *>(&f.refl[r.slot]);
+        const float so_far = seen == ~0ull ? RT_FLT_MAX : __uint_as_float((unsigned)(seen >> 32));
+        const bool meets = r.active && chunk_may_hit(s, chunk, r.hit, r.dir, so_far);
         if (!__syncthreads_or(meets ? 1 : 0)) continue;   // (also: everybody is done with the staged chunk)
         const int base = chunk * RT_CHUNK, cnt = min(RT_CHUNK, nsp - base);
         stage_chunk(L, s, base, cnt);
