@@ -25,7 +25,7 @@
 #include <vector>
 
 // Scratch of rt_render_rows_device_noalloc, the entry point that allocates nothing: the ray
-// queues, occlusion words and control block of ONE frame of bounded size.  Every GPU the library
+// queues and control block of ONE frame of bounded size.  Every GPU the library
 // runs on holds its own copy of this array from the moment the library is loaded until the
 // process ends.  In host code the array's name is only a handle for hipGetSymbolAddress: the
 // address the kernels get is the one that call returned for the device in question

@@ -37,7 +37,7 @@
 #define RT_MF_TEX_SHIFT   4        // texture slot + 1 in bits 4..7 (0 = none)
 #define RT_MF_TEX_MASK    0xF0
 
-// sph, sph_f, sph_cam and sph_orig are padded to a multiple of RT_SPH_PAD entries (a whole
+// sph, sph_f and sph_orig are padded to a multiple of RT_SPH_PAD entries (a whole
 // number of trips of bounding balls); the padding is {0, 0, 0, -inf}, which no ray passes in
 // the sphere filter, and so are the balls of groups made of padding only.
 #define RT_GROUP 8

@@ -2283,9 +2283,9 @@ k_lit(DevScene s, DevFrame f, int level)
 //   * a taker (thread 0) reads open_level with a device-scope load on every claim and reads a
 //     newly opened level's record counts before it hands tiles of that level to the workgroup.
 //     No cache invalidation is needed either: the records are read with device-scope loads
-//     (load_record), a record's occlusion words have one writer (plain stores, read by the
-//     shading launches), and the levels' slot ranges start at multiples of RT_LEVEL_ALIGN
-//     slots, so no cache line of a per-slot array holds slots of two levels.
+//     (load_record), a reflected colour and the zero it replaces are both written through
+//     (store_record), and the levels' slot ranges start at multiples of RT_LEVEL_ALIGN slots,
+//     so no cache line of a per-slot array holds slots of two levels.
 // The chain ends at the first open level without A records (level max_depth never has any);
 // a workgroup leaves when the chain has ended and no B tile is left to claim.  A workgroup
 // that has waited DevFrame::stall_ticks (wall clock, about a second) for a level to open without
