@@ -60,11 +60,11 @@ SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 2.0
 FLOP_SPHERE, FLOP_PLANE, FLOP_TRIANGLE, FLOP_LIGHT_SHADE = 25.0, 13.0, 51.0, 80.0
 
 CONFIGS = {
-    # BASELINE.json configs[2]: the configuration the headline metric is quoted on.
+    # The configuration the headline metric is quoted on.
     "c3": dict(width=3840, height=2160, max_depth=4, scene=scene_1k, cpu_row_step=1, cpu_mode="literal",
                workload="synthetic 1k-sphere scene (1000 spheres + 6 planes, 2 lights), 3840x2160, 4 mirror bounces",
                pmc="r02_c3_trace_pmc.json"),
-    # BASELINE.json configs[4]: divergence / occupancy stress.
+    # Divergence / occupancy stress.
     "c5": dict(width=1920, height=1080, max_depth=8, scene=scene_64k, cpu_row_step=54, cpu_mode="memoised",
                workload="synthetic 64k-sphere scene (65536 spheres + 6 planes, 16 lights), 1920x1080, 8 mirror bounces",
                pmc="r02_c5_trace_pmc.json"),

@@ -700,9 +700,10 @@ void build_light_tables(PackedScene &out)
     size_t total = 0;
     for (const PerLight &pl : per) total += pl.cell.size();
     if (total >= (size_t)1 << 31) throw std::length_error("the per-light occluder lists exceed 2^31 entries");
-    out.lt_sph.resize(total);
-    out.lt_orig.resize(total);
-    out.lt_reach.resize(total);
+    // (followed by entries that never occlude: the kernels load a little past a list's end)
+    out.lt_sph.assign(total + RT_LT_PAD, float4{0.f, 0.f, 0.f, -INFINITY});
+    out.lt_orig.assign(total + RT_LT_PAD, INT_MAX);
+    out.lt_reach.assign(total + RT_LT_PAD, INFINITY);
     size_t base = 0;
     for (size_t l = 0; l < nl; l++) {
         const PerLight &pl = per[l];
@@ -1131,6 +1132,11 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     fr.split_chunks = !fused && split_env && d.scene.ns_padded > RT_CHUNK ? 1 : 0;
     const int split_below_env = split_below_str ? atoi(split_below_str) : 0;
     fr.split_below = split_below_env > 0 ? split_below_env : std::max(1, d.num_cus * 2 / share);
+    // Scenes of one chunk, one launch per level: a level with fewer reflecting tiles than this is traced 64
+    // records per workgroup, the scene spread over the workgroup's waves.  RT_HIP_SPREAD_BELOW=n (tuning
+    // aid; 0 = never).
+    const char *spread_below_str = getenv("RT_HIP_SPREAD_BELOW");
+    fr.spread_below = fused ? 0 : spread_below_str ? atoi(spread_below_str) : std::max(1, d.num_cus * 2 / share);
     // Scenes with several lights, one launch per level: short queues are shaded with the lights spread
     // over the waves of a workgroup (k_shade_lights).  RT_HIP_LIGHT_SPLIT_BELOW=n (tuning aid; 0 = never).
     const char *light_below_str = getenv("RT_HIP_LIGHT_SPLIT_BELOW");   // (these knobs are read at every call)

@@ -165,6 +165,9 @@ struct DevSched {
 //                                         the pixel index at level 0 (int bits)
 //   refl[slot] = {rgb of the reflected Shade(), valid}   written by the child
 #define RT_LEVEL_ALIGN 64
+// The per-light occluder lists (lt_sph, lt_reach, lt_orig) end with this many entries that never occlude:
+// a lane may load up to that far past the end of its own list.
+#define RT_LT_PAD 8
 #define RT_BIN_AXIS 16                                         // position bins per axis
 #define RT_BINS (RT_BIN_AXIS * RT_BIN_AXIS * RT_BIN_AXIS)      // per queue
 struct DevFrame {
@@ -201,6 +204,8 @@ struct DevFrame {
     float4 *lit;
     int light_waves;       // > 0: queues of fewer than light_split_below records are shaded with the lights spread
     int light_split_below; // over that many waves per 64 records (k_shade_lights)
+    int spread_below;      // one-chunk scenes: levels with fewer reflecting tiles than this take 64 records per workgroup
+                           // and spread the scene over its waves (k_reflect)
     int split_chunks;      // 1: levels with fewer than split_below reflecting tiles are traced one (tile, chunk)
     int split_below;       // job at a time (k_reflect_chunks): new reflecting records get their closest-hit word
                            // initialised in refl[]

@@ -719,6 +719,8 @@ __device__ __forceinline__ void gather_pass_bits(const int *cand, const int ntri
 //   SPLIT true (trace rays): with more lights the rays of a record point in unrelated
 //     directions, so at level 3 every ray k has its own bitmap and runs only the groups IT may
 //     hit, one ray per SEL loop; exact(RayIndex<k>, sphere, host index) evaluates ray k.
+// run_mask: the runs of RT_SUPER spheres this call is to look at, in the bit order of level 1's
+// result (bit 8t + 7 - m = run 8t + m); the spheres of the other runs are left to other callers.
 // lane_s / lane_g: the per-origin operands of the two ball levels (trace rays).  The sphere's
 // {centre, r*r} and host primitive index come from sph / orig (the chunk's part of
 // DevScene::sph / sph_orig).  The order of the calls is not the spheres' host order.  Every lane
@@ -727,7 +729,7 @@ template <int K, bool TRACE, bool SPLIT, class Exact>
 __device__ __forceinline__ void walk_chunk(WalkLds &L, const int cnt, const float4 *sph, const int *orig,
                                            const f4raw (&rq)[4], const f4raw lane_s, const f4raw lane_g,
                                            const f4raw lane, FilterWork &fw, PhaseClock &pc, Exact &&exact,
-                                           const unsigned (&live)[4])
+                                           const unsigned (&live)[4], const unsigned run_mask = ~0u)
 {
     static_assert(TRACE || !SPLIT, "primary rays use the combined loops");
     constexpr bool split = SPLIT && K > 1;
@@ -749,6 +751,7 @@ __device__ __forceinline__ void walk_chunk(WalkLds &L, const int cnt, const floa
         runs = 0u;
 #pragma unroll
         for (int k = 0; k < NB; k++) runs |= any[k][0];   // bit 8t + 7 - m = run 8t + m
+        runs &= run_mask;   // (a wave that shares the chunk with others walks only its own runs)
     }
     // Level 2: the groups' balls of those runs; the slots of the other trips read "all rejected".
 #pragma unroll
@@ -1468,17 +1471,24 @@ __device__ __forceinline__ int light_occluder(const DevScene &s, const uint2 cel
     int first = INT_MAX;
     // The list's first entries are fetched before the planes and triangles are tested, so that their
     // way from memory is covered by that arithmetic (cell: the light's table cell for this origin,
-    // which the caller fetched while it shaded the previous light).
-    const float4 none = make_float4(0.f, 0.f, 0.f, -INFINITY);   // never occludes
+    // which the caller fetched while it shaded the previous light).  Every lane loads, whatever its
+    // list's length: the lists are followed by RT_LT_PAD entries that never occlude, an index is
+    // held to "one past this lane's list", and what a lane has no use for is never looked at
+    // (k + j < cnt below) - straight-line loads instead of a branch around every one of them.
+    const bool tables = s.lt_n > 0;   // (wave-uniform)
     const float4 *list = s.lt_sph + cell.x;
     const float *reach = s.lt_reach + cell.x;
-    const int cnt0 = s.lt_n > 0 && active && !far ? (int)cell.y : 0;
+    const int len = (int)cell.y;
+    const int cnt0 = tables && active && !far ? len : 0;
     float4 nxt[LIGHT_BATCH];
     float nxt_reach[LIGHT_BATCH];
+    static_assert(LIGHT_BATCH <= RT_LT_PAD, "the first batch is loaded without looking at the list's length");
+    if (tables) {
 #pragma unroll
-    for (int j = 0; j < LIGHT_BATCH; j++) {
-        nxt[j] = j < cnt0 ? list[j] : none;
-        nxt_reach[j] = j < cnt0 ? reach[j] : 0.0f;
+        for (int j = 0; j < LIGHT_BATCH; j++) {
+            nxt[j] = list[j];
+            nxt_reach[j] = reach[j];
+        }
     }
     for (int j = 0; j < s.np; j++) {
         const float4 pl = cload(s.pl, j);
@@ -1490,7 +1500,7 @@ __device__ __forceinline__ int light_occluder(const DevScene &s, const uint2 cel
         float t;
         if (triangle_t(e1, e2, sub3(hit, v0), d, t) && t > RT_EPS && t < dist) first = min(first, cload(s.tri_orig, j));
     }
-    if (s.lt_n > 0) {
+    if (tables) {
         int cnt = !COUNT && first != INT_MAX ? 0 : cnt0;
         // LIGHT_BATCH entries per step, the next step's loads in flight while this step's entries are
         // evaluated: a list is walked at the pace of the arithmetic, not of one memory round trip
@@ -1505,8 +1515,14 @@ __device__ __forceinline__ int light_occluder(const DevScene &s, const uint2 cel
             for (int j = 0; j < LIGHT_BATCH; j++) {
                 sp[j] = nxt[j];
                 sp_reach[j] = nxt_reach[j];
-                nxt[j] = k + LIGHT_BATCH + j < cnt ? list[k + LIGHT_BATCH + j] : none;
-                nxt_reach[j] = k + LIGHT_BATCH + j < cnt ? reach[k + LIGHT_BATCH + j] : 0.0f;
+            }
+            if (__ballot(k + LIGHT_BATCH < cnt) != 0ull) {
+#pragma unroll
+                for (int j = 0; j < LIGHT_BATCH; j++) {
+                    const int i = min(k + LIGHT_BATCH + j, len);
+                    nxt[j] = list[i];
+                    nxt_reach[j] = reach[i];
+                }
             }
 #pragma unroll
             for (int j = 0; j < LIGHT_BATCH; j++) {
@@ -1862,6 +1878,96 @@ __device__ __forceinline__ void reflection_tile(const DevScene &s, const DevFram
     PHASE_MARK(pc, 7)
 }
 
+// A closest hit as one word: t > 0, so the keys' order is the order of (t, host index).
+__device__ __forceinline__ unsigned long long hit_key(const float t, const int prim)
+{
+    return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned)prim;
+}
+
+// The same for a level of few records, 64 records per workgroup instead of 256: every wave takes
+// the SAME 64 records and a quarter of the scene (the runs of RT_SUPER spheres r with r % 4 = its
+// number, every fourth plane and triangle), the waves' closest hits meet in LDS as 64-bit keys
+// (hit_key: their order is the order Scene.Intersect's strict `<` implies), and wave 0 pushes the
+// children.  A wave alone on its SIMD issues an instruction every ~5 cycles, and the rays of a deep
+// level have so little in common that a wave ends up testing most of the scene's spheres: a tile
+// of a 1000-sphere scene takes ~40 us however few tiles the level has; four waves with a quarter of
+// the spheres each take a third of that.  best: a __shared__ array of 64 keys.
+__device__ __forceinline__ void reflection_tile_spread(const DevScene &s, const DevFrame &f, WalkLds &L, int *blk,
+                                                       unsigned long long *best, const int level, const int tile,
+                                                       const int n, TestCount &tc, PhaseClock &pc)
+{
+    PHASE_MARK(pc, 0)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = tile * 64 + lane;
+    const bool active = i < n;
+    const int slot = level * f.P + (active ? i : n - 1);
+    float4 ra, rb;
+    load_record(&f.recA[slot], &f.recB[slot], ra, rb);
+    const f3 hit = xyz(ra), view = xyz(rb);
+    const int prim = __float_as_int(ra.w);
+    const int type = __float_as_int(cload(s.mat, 3 * prim + 1).w) & RT_MF_TYPE_MASK;
+    const f3 normal = record_normal(s, prim, type, hit);
+    // objects.cs:82: (viewDir - 2 * Dot(viewDir, normal) * normal).Normalized()
+    const f3 dir = normalized3(sub3(view, scale3(normal, 2.0f * dot3(view, normal))));
+    const float a = dot3(dir, dir);
+    if (wave == 0) best[lane] = ~0ull;
+    __syncthreads();
+    Closest sec = {RT_FLT_MAX, INT_MAX};
+    FilterWork fw = {0, 0, 0};
+    if (s.ns_padded > 0) {
+        const FilterOrigin fo = filter_origin(s, hit);
+        f4raw rq[4];
+        rq[0] = filter_ray(fo, dir);
+#pragma unroll
+        for (int l = 1; l < 4; l++) rq[l] = f4raw{0.f, 0.f, 0.f, 0.f};
+        // Sphere.Intersect objects.cs:112-121, literally; equal distances: the lower host index.
+        auto exact = [&](auto, const float4 sp, const int orig) {
+            const f3 op = sub3(hit, xyz(sp));
+            const float c = dot3(op, op) - sp.w;
+            const float x = dot3(dir, op);
+            float t;
+            if (sphere_maybe(x, a * c) && sphere_root(x, c, a, t)) closest_offer(sec, t, orig);
+        };
+        const unsigned live[4] = {~0u, ~0u, ~0u, ~0u};
+        walk_chunk<1, true, false>(L, s.ns_padded, s.sph, s.sph_orig, rq, fo.lane_s, fo.lane_g, fo.lane, fw, pc, exact,
+                                   live, 0x88888888u >> wave);
+    }
+    PHASE_MARK(pc, 5)
+    for (int j = wave; j < s.np; j += 4) {
+        const float4 pl = cload(s.pl, j);
+        const f3 nn = xyz(pl);
+        float t;
+        if (plane_t(nn, (-dot3(nn, hit)) - pl.w, dir, t)) closest_offer(sec, t, cload(s.pl_orig, j));
+    }
+    for (int j = wave; j < s.nt; j += 4) {
+        const f3 v0 = xyz(cload(s.tri, 3 * j)), e1 = xyz(cload(s.tri, 3 * j + 1)), e2 = xyz(cload(s.tri, 3 * j + 2));
+        float t;
+        if (triangle_t(e1, e2, sub3(hit, v0), dir, t)) closest_offer(sec, t, cload(s.tri_orig, j));
+    }
+    if (sec.prim != INT_MAX) atomicMin(&best[lane], hit_key(sec.t, sec.prim));
+    __syncthreads();
+    PHASE_MARK(pc, 6)
+    const unsigned long long key = best[lane];
+    const float t = key == ~0ull ? RT_FLT_MAX : __uint_as_float((unsigned)(key >> 32));
+    const int hit_prim = key == ~0ull ? INT_MAX : (int)(unsigned)key;
+    if (active && wave == 0) {
+        tc.sph += s.ns;
+        tc.pl += s.np;
+        tc.tri += s.nt;
+    }
+    tc.exact += active ? fw.candidates : 0;
+    tc.filt_terms += fw.terms;
+    tc.filt_rays += fw.ray_tests;
+    const bool child = active && wave == 0 && hit_prim != INT_MAX;
+    const f3 hit2 = add3(hit, scale3(dir, t));   // objects.cs:123,166,263
+    if (active && wave == 0) store_record(&f.refl[slot], f4raw{0.0f, 0.0f, 0.0f, 0.0f});   // (see reflection_tile)
+    const bool rv[1] = {child};
+    const int rp[1] = {child ? hit_prim : 0}, rparent[1] = {slot};
+    const f3 rh[1] = {hit2}, rd[1] = {dir};
+    push_records<1>(f, s, level + 1, blk, rv, rp, rh, rd, rparent);
+    PHASE_MARK(pc, 7)
+}
+
 // plain_tile: records without a reflection trace (queue "B") depend on nothing further: they are
 // shaded on the spot (light rays included) and their colour goes to the parent record or pixel.
 template <bool COUNT>
@@ -1902,14 +2008,32 @@ __global__ void __launch_bounds__(256) k_reflect(DevScene s, DevFrame f, int lev
     const int n = f.cnt[2 * level];
     const int ntiles = (n + 255) >> 8;
     if (MULTI && f.split_chunks && ntiles < f.split_below) return;   // k_reflect_chunks takes this level
-    if (!MULTI && (int)blockIdx.x < ntiles) {
+    // One chunk and too few tiles to fill the device: 64 records per workgroup, the scene spread over its waves.
+    const bool spread = !MULTI && ntiles < f.spread_below;
+    const int nwork = spread ? (n + 63) >> 6 : ntiles;
+    if (!MULTI && (int)blockIdx.x < nwork) {
         stage_chunk(L, s, 0, s.ns_padded);
         __syncthreads();
     }
     TestCount tc = {0, 0, 0, 0, 0, 0, 0};
     PhaseClock pc = {};
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) reflection_tile<MULTI>(s, f, L, blk, level, tile, n, tc, pc);
+#ifdef RT_PHASE_CLOCKS
+    pc.t_last = __builtin_readcyclecounter();
+#endif
+    if constexpr (!MULTI) {
+        if (spread) {
+            __shared__ unsigned long long best[64];
+            for (int tile = blockIdx.x; tile < nwork; tile += gridDim.x)
+                reflection_tile_spread(s, f, L, blk, best, level, tile, n, tc, pc);
+        }
+    }
+    if (!spread)
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) reflection_tile<MULTI>(s, f, L, blk, level, tile, n, tc, pc);
+#ifdef RT_PHASE_CLOCKS
+    if ((int)blockIdx.x < nwork) flush_counters(f, cnt_sh, pc.clk);
+#else
     if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1927,10 +2051,6 @@ __global__ void __launch_bounds__(256) k_reflect(DevScene s, DevFrame f, int lev
 // implies (MyApplication.cs:361).  k_reflect_finish then adds planes and triangles, and pushes
 // the next level's records, as k_reflect does.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long hit_key(const float t, const int prim)
-{
-    return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned)prim;
-}
 
 // The mirror direction of a record and what it starts from.
 struct ReflectionRay {

@@ -2,8 +2,8 @@
  * abi_consumer.c — a plain-C host of librt_hip.so: the closest thing to the C# host's P/Invoke
  * binding this image can compile.  Built with `gcc -std=c99 -Wall -Werror -pedantic` against
  * include/rt_hip.h only (tests/test_abi_consumer.py), so the header is exercised as C, its struct
- * layouts are pinned at compile time to what the `StructLayout(LayoutKind.Sequential)` structs of
- * INTEGRATION.md assume, and a frame goes through the same calls the host edit makes:
+ * layouts are pinned at compile time to what `StructLayout(LayoutKind.Sequential)` structs on the
+ * C# side would assume, and a frame goes through the same calls that host makes:
  * rt_create, rt_set_scene, rt_render, rt_get_stats, rt_last_error, rt_destroy.
  *
  * usage: abi_consumer scene.bin width height max_depth expected.raw
