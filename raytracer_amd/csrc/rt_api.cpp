@@ -41,10 +41,11 @@ unsigned char *g_scratch_address[RT_SCRATCH_TABLE] = {};
 
 constexpr int RT_CHAIN_RESERVED_TILES_PER_WORKGROUP = 6;
 // Below this many level-0 tiles per workgroup of the level kernel that the whole device holds, a
-// frame is rendered "fused" (enqueue_rows).  Measured on MI355X, 3840x2160 / G, ms per frame with
-// 1 / 2 / 3 frames in flight — G = 8 (4 tiles): levels 0.33 / 0.28 / 0.18, fused 0.34 / 0.20 /
-// 0.15; G = 4 (8 tiles): levels 0.39 / 0.33 / 0.21, fused 0.44 / 0.28 / 0.24; G = 1: levels 0.75,
-// fused 1.12.
+// frame of a context that shares its device with three or more others is rendered "fused"
+// (enqueue_rows).  Measured on MI355X, 3840x2160 / G, ms per frame with 1 / 2 / 3 / 4 frames in
+// flight - G = 8 (4 tiles): levels 0.20 / 0.16 / 0.13 / 0.127, fused 0.33 / 0.18 / 0.14 / 0.106;
+// G = 4 (8 tiles): levels 0.26 / 0.23 / 0.18 / 0.17, fused 0.42 / 0.26 / 0.21 / 0.18; G = 1: levels
+// 0.61, fused 1.07.
 constexpr int RT_FUSED_BELOW_TILES_PER_WORKGROUP = 6;
 
 // Counter slots + level schedule + two record counts per level (DevFrame::counters, sched, cnt).
@@ -1122,8 +1123,13 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     fr.debug_withhold = withhold_env ? atoi(withhold_env) : -1;
     const char *pipeline_env = getenv("RT_HIP_PIPELINE");   // (read at every call; see below)
     static const bool level_kernels = getenv("RT_HIP_LEVEL_KERNELS") != nullptr;
+    // (the fused form pays only where several small frames are in flight on the device at once - there its
+    // single launch per frame beats the levels' chains of short launches, 1/8 of the 4K frame with four in
+    // flight: 0.106 against 0.127 ms - and the scene is one chunk; a frame alone on the device: 0.33 against
+    // 0.20 ms, 256x256 of the 64k-sphere scene: 9.1 against 1.5 ms)
     const bool fused = pipeline_env ? strcmp(pipeline_env, "fused") == 0
-                                    : !level_kernels && tiles0 < RT_FUSED_BELOW_TILES_PER_WORKGROUP * resident(false);
+                                    : !level_kernels && share >= 4 && d.scene.ns_padded <= RT_CHUNK &&
+                                          tiles0 < RT_FUSED_BELOW_TILES_PER_WORKGROUP * resident(false);
     // Scenes of several chunks, one launch per level: the reflection rays of a level are traced as
     // (tile, chunk) jobs (k_reflect_chunks).  RT_HIP_SPLIT_CHUNKS=0 (tuning aid) keeps a tile's chunks
     // to its own workgroup.
