@@ -93,7 +93,7 @@ def build_tools(force: bool = False) -> None:
         if not force and os.path.exists(exe) and os.path.getmtime(exe) >= os.path.getmtime(path):
             continue
         subprocess.run([hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off",
-                        "-fno-slp-vectorize", "-Wno-unused-result", path, "-o", exe], check=True)
+                        "-fno-slp-vectorize", "-Wno-unused-result", "-I", CSRC, path, "-o", exe], check=True)
 
 
 if __name__ == "__main__":
