@@ -295,6 +295,13 @@ struct PackedScene {
     std::vector<float> lt_reach;
     int lt_n = 0;
     float lt_near = 0.f;
+    // Uniform grid over the spheres (build_sphere_grid).
+    std::vector<uint2> gr_cells;
+    std::vector<float4> gr_sph;
+    std::vector<int> gr_orig;
+    int gr_n[3] = {0, 0, 0};
+    float gr_lo[3] = {0.f, 0.f, 0.f}, gr_ih[3] = {0.f, 0.f, 0.f};
+    float gr_reg_lo[3] = {0.f, 0.f, 0.f}, gr_reg_hi[3] = {0.f, 0.f, 0.f};
 };
 
 bool usable_sphere(const float4 &s)
@@ -729,6 +736,163 @@ void build_light_tables(PackedScene &out)
     out.lt_near = (float)(near * (1.0 - 1e-6));
 }
 
+// ---------------------------------------------------------------------------------------
+// Uniform grid over the spheres: what a reflection ray's closest-hit search walks instead of the
+// whole scene (rt_kernels.hip, "Grid walk").  A cell lists the spheres whose WIDENED box touches
+// it; the kernel runs the exact, literal Sphere.Intersect over the lists of the cells the ray
+// passes, nearest first, and stops once its closest hit so far lies before the parameter at which
+// it leaves the cells visited.  What makes that lose nothing the reference accepts:
+//   * If the reference accepts the pair (ray, sphere i) with parameter t_ref, the point o + t_ref d
+//     of the real ray lies in the ball of radius R_i = sqrt(r_i^2 + 28.6u B^2) + 8u B around the
+//     centre, B >= |o - p_i|, u = 2^-24 (the bound the sphere filter's proof gives for the line's
+//     distance from the centre, rt_kernels.hip "Bounding balls", plus the rounding of t_ref itself:
+//     the computed discriminant / 4 is at most r^2 - perp^2 + 20u B^2, so the computed hit lies
+//     no farther than that root from the point of closest approach).  The lists are built with
+//     B = the largest distance between an origin in the served region (gr_reg_lo .. gr_reg_hi) and
+//     a sphere centre; the kernel evaluates every sphere for origins outside that region.
+//   * The walk's cell sequence is that of a ray whose plane crossings are off by at most a few
+//     1e-4 cells (cell coordinates up to ~400 in magnitude, a handful of roundings): every point
+//     of the real ray up to the parameter at which the walk leaves a cell lies within GRID_EPS
+//     cells of a visited cell, and the boxes are widened by that much more.  So a sphere that is
+//     in none of the visited cells' lists is first met by the real ray beyond that parameter.
+// The grid is defined by the FP32 parameters the kernel uses (cell coordinate of x = (x - gr_lo) *
+// gr_ih in real arithmetic); the boxes are binned against those same numbers in double.
+// No grid (the kernels that walk the LDS-staged scene are used): fewer than RT_GRID_MIN_SPHERES usable
+// spheres, extents that are not finite, or lists that would grow out of proportion (a sphere that
+// covers thousands of cells).  RT_HIP_GRID=0 (tuning aid) turns it off; RT_HIP_GRID_DENSITY = cells
+// per sphere (default 4); RT_HIP_GRID_REGION = how far the served region reaches beyond the spheres'
+// extent, in units of its largest side (default 0.5).
+// ---------------------------------------------------------------------------------------
+constexpr size_t RT_GRID_MIN_SPHERES = 64;
+constexpr int RT_GRID_MAX_AXIS = 256;
+constexpr double GRID_EPS = 4e-3;   // cells
+
+void build_sphere_grid(PackedScene &out)
+{
+    out.gr_cells.clear();
+    out.gr_sph.clear();
+    out.gr_orig.clear();
+    out.gr_n[0] = out.gr_n[1] = out.gr_n[2] = 0;
+    const char *env = getenv("RT_HIP_GRID");
+    if (env && atoi(env) == 0) return;
+    const char *dens_env = getenv("RT_HIP_GRID_DENSITY"), *reg_env = getenv("RT_HIP_GRID_REGION");
+    const double density = dens_env && atof(dens_env) > 0.0 ? atof(dens_env) : 4.0;
+    const double reach = reg_env && atof(reg_env) >= 0.0 ? atof(reg_env) : 0.5;
+    const double u24 = 1.0 / 16777216.0;
+    std::vector<uint32_t> use;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = 0; i < out.sph.size(); i++) {
+        const float4 &sp = out.sph[i];
+        if (!usable_sphere(sp) || out.sph_orig[i] == INT32_MAX) continue;
+        use.push_back((uint32_t)i);
+        const double c[3] = {sp.x, sp.y, sp.z};
+        for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], c[k]), hi[k] = std::max(hi[k], c[k]);
+    }
+    if (use.size() < RT_GRID_MIN_SPHERES) return;
+    double ext = 0.0;
+    for (int k = 0; k < 3; k++) ext = std::max(ext, hi[k] - lo[k]);
+    if (!std::isfinite(ext) || !(ext > 0.0)) return;
+    // The served region of origins and the bound B it implies (per axis: centre and origin both lie
+    // within the region, the centre within the centres' extent).
+    double reg_lo[3], reg_hi[3], B2 = 0.0;
+    for (int k = 0; k < 3; k++) {
+        reg_lo[k] = lo[k] - reach * ext;
+        reg_hi[k] = hi[k] + reach * ext;
+        const double span = (hi[k] - lo[k]) + reach * ext;
+        B2 += span * span;
+    }
+    const double Bmax = std::sqrt(B2) * (1.0 + 1e-6);
+    auto widened = [&](const float4 &sp) {
+        return (std::sqrt((double)sp.w + 28.6 * u24 * Bmax * Bmax) + 8.0 * u24 * Bmax) * (1.0 + 1e-6) + 1e-6 * Bmax;
+    };
+    double glo[3] = {INFINITY, INFINITY, INFINITY}, ghi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (const uint32_t i : use) {
+        const float4 &sp = out.sph[i];
+        const double R = widened(sp), c[3] = {sp.x, sp.y, sp.z};
+        for (int k = 0; k < 3; k++) glo[k] = std::min(glo[k], c[k] - R), ghi[k] = std::max(ghi[k], c[k] + R);
+    }
+    double vol = 1.0, side[3];
+    for (int k = 0; k < 3; k++) {
+        side[k] = ghi[k] - glo[k];
+        if (!std::isfinite(side[k]) || !(side[k] > 0.0)) return;
+        vol *= side[k];
+    }
+    const double h = std::cbrt(vol / (density * (double)use.size()));
+    if (!std::isfinite(h) || !(h > 0.0)) return;
+    int n[3];
+    float lo_f[3], ih_f[3];
+    for (int k = 0; k < 3; k++) {
+        n[k] = (int)std::min<double>(RT_GRID_MAX_AXIS, std::max(1.0, std::ceil(side[k] / h)));
+        // One per cent of a cell of room on either side of the boxes, then FP32 parameters that
+        // still cover them: the corner rounded down, the scale rounded towards zero.
+        const double cell = side[k] / n[k];
+        const double l = glo[k] - 0.01 * cell - 1e-6 * std::fabs(glo[k]), hgh = ghi[k] + 0.01 * cell + 1e-6 * std::fabs(ghi[k]);
+        lo_f[k] = std::nextafter((float)l, -INFINITY);
+        ih_f[k] = std::nextafter((float)((double)n[k] / (hgh - (double)lo_f[k]) * (1.0 - 1e-6)), 0.f);
+        if (!std::isfinite(lo_f[k]) || !std::isfinite(ih_f[k]) || !(ih_f[k] > 0.f)) return;
+        if (((double)ghi[k] - (double)lo_f[k]) * (double)ih_f[k] > (double)n[k] - 0.005) return;   // (cannot happen)
+    }
+    const size_t ncells = (size_t)n[0] * n[1] * n[2];
+    // Cell ranges of the boxes.
+    struct Range { int a[3], b[3]; };
+    std::vector<Range> ranges(use.size());
+    size_t total = 0;
+    for (size_t j = 0; j < use.size(); j++) {
+        const float4 &sp = out.sph[use[j]];
+        const double R = widened(sp), c[3] = {sp.x, sp.y, sp.z};
+        size_t cover = 1;
+        for (int k = 0; k < 3; k++) {
+            const double a = ((c[k] - R) - (double)lo_f[k]) * (double)ih_f[k] - GRID_EPS;
+            const double b = ((c[k] + R) - (double)lo_f[k]) * (double)ih_f[k] + GRID_EPS;
+            ranges[j].a[k] = (int)std::min<double>(n[k] - 1, std::max(0.0, std::floor(a)));
+            ranges[j].b[k] = (int)std::min<double>(n[k] - 1, std::max(0.0, std::floor(b)));
+            cover *= (size_t)(ranges[j].b[k] - ranges[j].a[k] + 1);
+        }
+        if (cover > 4096) return;   // a sphere far larger than the cells: the lists would be the scene
+        total += cover;
+    }
+    if (total > 64 * use.size() + 4096 || total >= ((size_t)1 << 30)) return;
+    out.gr_cells.assign(ncells, uint2{0u, 0u});
+    auto cell_of = [&](int x, int y, int z) { return ((size_t)z * n[1] + y) * n[0] + x; };
+    for (const Range &r : ranges)
+        for (int z = r.a[2]; z <= r.b[2]; z++)
+            for (int y = r.a[1]; y <= r.b[1]; y++)
+                for (int x = r.a[0]; x <= r.b[0]; x++) out.gr_cells[cell_of(x, y, z)].y++;
+    // Every list starts at an even entry (the kernel loads its entries in pairs); the gaps and the
+    // arrays' ends hold entries that can never be hit.
+    size_t off = 0;
+    for (uint2 &c : out.gr_cells) {
+        c.x = (uint32_t)off;
+        off += (c.y + 1u) & ~1u;
+        c.y = 0;
+    }
+    if (off >= ((size_t)1 << 31)) {
+        out.gr_cells.clear();
+        return;
+    }
+    out.gr_sph.assign(off + RT_GRID_PAD, float4{0.f, 0.f, 0.f, -INFINITY});
+    out.gr_orig.assign(off + RT_GRID_PAD, INT32_MAX);
+    for (size_t j = 0; j < use.size(); j++) {
+        const Range &r = ranges[j];
+        for (int z = r.a[2]; z <= r.b[2]; z++)
+            for (int y = r.a[1]; y <= r.b[1]; y++)
+                for (int x = r.a[0]; x <= r.b[0]; x++) {
+                    uint2 &c = out.gr_cells[cell_of(x, y, z)];
+                    out.gr_sph[(size_t)c.x + c.y] = out.sph[use[j]];
+                    out.gr_orig[(size_t)c.x + c.y] = out.sph_orig[use[j]];
+                    c.y++;
+                }
+    }
+    for (int k = 0; k < 3; k++) {
+        out.gr_n[k] = n[k];
+        out.gr_lo[k] = lo_f[k];
+        out.gr_ih[k] = ih_f[k];
+        // (rounded inwards)
+        out.gr_reg_lo[k] = std::nextafter((float)reg_lo[k], INFINITY);
+        out.gr_reg_hi[k] = std::nextafter((float)reg_hi[k], -INFINITY);
+    }
+}
+
 int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
 {
     const int n = s->num_prims, nl = s->num_lights;
@@ -806,6 +970,7 @@ int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
         out.light_col[l] = make_float4(c[0], c[1], c[2], c[3]);
     }
     build_light_tables(out);
+    build_sphere_grid(out);
     return RT_OK;
 }
 
@@ -846,6 +1011,16 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     if ((rc = upload(ctx, d, ps.lt_reach, &sc.lt_reach)) != RT_OK) return rc;
     sc.lt_n = ps.lt_n;
     sc.lt_near = ps.lt_near;
+    if ((rc = upload(ctx, d, ps.gr_cells, &sc.gr_cells)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.gr_sph, &sc.gr_sph)) != RT_OK) return rc;
+    if ((rc = upload(ctx, d, ps.gr_orig, &sc.gr_orig)) != RT_OK) return rc;
+    for (int k = 0; k < 3; k++) {
+        sc.gr_n[k] = ps.gr_n[k];
+        sc.gr_lo[k] = ps.gr_lo[k];
+        sc.gr_ih[k] = ps.gr_ih[k];
+        sc.gr_reg_lo[k] = ps.gr_reg_lo[k];
+        sc.gr_reg_hi[k] = ps.gr_reg_hi[k];
+    }
     sc.nsup_padded = (int)ps.sup_f.size();
     sc.nchk_padded = (int)ps.chk_f.size();
     sc.grp_rmax = ps.grp_rmax;
@@ -1122,27 +1297,28 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     const char *withhold_env = getenv("RT_HIP_DEBUG_WITHHOLD_LEVEL");
     fr.debug_withhold = withhold_env ? atoi(withhold_env) : -1;
     const char *pipeline_env = getenv("RT_HIP_PIPELINE");   // (read at every call; see below)
+    const bool grid = d.scene.gr_n[0] > 0;   // reflection rays walk the spheres' grid (k_reflect_grid): no chunks, no LDS
     static const bool level_kernels = getenv("RT_HIP_LEVEL_KERNELS") != nullptr;
     // (the fused form pays only where several small frames are in flight on the device at once - there its
     // single launch per frame beats the levels' chains of short launches, 1/8 of the 4K frame with four in
     // flight: 0.106 against 0.127 ms - and the scene is one chunk; a frame alone on the device: 0.33 against
     // 0.20 ms, 256x256 of the 64k-sphere scene: 9.1 against 1.5 ms)
     const bool fused = pipeline_env ? strcmp(pipeline_env, "fused") == 0
-                                    : !level_kernels && share >= 4 && d.scene.ns_padded <= RT_CHUNK &&
+                                    : !level_kernels && share >= 4 && (d.scene.ns_padded <= RT_CHUNK || grid) &&
                                           tiles0 < RT_FUSED_BELOW_TILES_PER_WORKGROUP * resident(false);
     // Scenes of several chunks, one launch per level: the reflection rays of a level are traced as
     // (tile, chunk) jobs (k_reflect_chunks).  RT_HIP_SPLIT_CHUNKS=0 (tuning aid) keeps a tile's chunks
     // to its own workgroup.
     const char *split_chunks_env = getenv("RT_HIP_SPLIT_CHUNKS"), *split_below_str = getenv("RT_HIP_SPLIT_BELOW");
     const bool split_env = !split_chunks_env || atoi(split_chunks_env) != 0;
-    fr.split_chunks = !fused && split_env && d.scene.ns_padded > RT_CHUNK ? 1 : 0;
+    fr.split_chunks = !fused && !grid && split_env && d.scene.ns_padded > RT_CHUNK ? 1 : 0;
     const int split_below_env = split_below_str ? atoi(split_below_str) : 0;
     fr.split_below = split_below_env > 0 ? split_below_env : std::max(1, d.num_cus * 2 / share);
     // Scenes of one chunk, one launch per level: a level with fewer reflecting tiles than this is traced 64
     // records per workgroup, the scene spread over the workgroup's waves.  RT_HIP_SPREAD_BELOW=n (tuning
     // aid; 0 = never).
     const char *spread_below_str = getenv("RT_HIP_SPREAD_BELOW");
-    fr.spread_below = fused ? 0 : spread_below_str ? atoi(spread_below_str) : std::max(1, d.num_cus * 2 / share);
+    fr.spread_below = fused || grid ? 0 : spread_below_str ? atoi(spread_below_str) : std::max(1, d.num_cus * 2 / share);
     // Scenes with several lights, one launch per level: short queues are shaded with the lights spread
     // over the waves of a workgroup (k_shade_lights).  RT_HIP_LIGHT_SPLIT_BELOW=n (tuning aid; 0 = never).
     const char *light_below_str = getenv("RT_HIP_LIGHT_SPLIT_BELOW");   // (these knobs are read at every call)

@@ -91,6 +91,18 @@ struct DevScene {
                               // (widened) sphere; a cell's entries are sorted by it
     int lt_n;
     float lt_near;
+    // Uniform grid over the spheres (rt_api.cpp, build_sphere_grid; rt_kernels.hip, "Grid walk"): cell
+    // (x, y, z) = gr_cells[(z * gr_n[1] + y) * gr_n[0] + x] = {first entry, entries} of the spheres whose
+    // widened box touches the cell: gr_sph {centre, r*r} and gr_orig (host primitive index) per entry.  The
+    // lists hold every sphere the reference can accept for a ray whose ORIGIN lies in the box gr_reg_lo ..
+    // gr_reg_hi; other origins evaluate every sphere.  gr_n[0] = 0: no grid.
+    const uint2 *gr_cells;
+    const float4 *gr_sph;
+    const int *gr_orig;
+    int gr_n[3];
+    float gr_lo[3];           // the grid's lower corner
+    float gr_ih[3];           // cells per unit of length
+    float gr_reg_lo[3], gr_reg_hi[3];
     // Position bins (k_bin_*): cell of a point = floor((p - bin_lo) * bin_scale) per axis, clamped to
     // 0 .. RT_BIN_AXIS - 1; the box is the spheres' extent.  bin_scale[0] = 0: no box.
     float bin_lo[3], bin_scale[3];
@@ -127,7 +139,8 @@ struct DevCounters {
     unsigned long long plane_tests;
     unsigned long long triangle_tests;
     unsigned long long exact_candidates;   // (ray origin, sphere) pairs evaluated exactly
-    unsigned long long filter_ray_tests;   // (ray, sphere or ball) pairs the filter evaluated
+    unsigned long long filter_ray_tests;   // (ray, sphere or ball) pairs the filter evaluated, plus the cells the
+                                           // reflection rays' grid walks visited
     unsigned long long filter_origin_terms;   // (origin, sphere or ball) per-origin terms formed
     unsigned long long primary_filter_ray_tests;   // the primary kernel's share of filter_ray_tests
     unsigned long long primary_exact_candidates;   // ... and of exact_candidates
@@ -168,6 +181,9 @@ struct DevSched {
 // The per-light occluder lists (lt_sph, lt_reach, lt_orig) end with this many entries that never occlude:
 // a lane may load up to that far past the end of its own list.
 #define RT_LT_PAD 8
+// The grid's entry arrays (gr_sph, gr_orig) end with this many entries that can never be hit: the walk loads
+// its entries in pairs.
+#define RT_GRID_PAD 4
 #define RT_BIN_AXIS 16                                         // position bins per axis
 #define RT_BINS (RT_BIN_AXIS * RT_BIN_AXIS * RT_BIN_AXIS)      // per queue
 struct DevFrame {

@@ -1244,6 +1244,7 @@ struct TestCount {
     int filt_terms;   // spheres and balls this lane formed the filter's per-origin term for
     int filt_rays;    // (ray, sphere or ball) pairs this lane's filter evaluated
     int shadow;       // (light ray, sphere) pairs this lane evaluated exactly from the lights' tables
+    int grid;         // cells this lane's grid walks visited
 };
 
 template <int LC, bool SEC>
@@ -1986,10 +1987,11 @@ __device__ __forceinline__ void flush_test_counts(const DevFrame &f, unsigned lo
 {
     static_assert(COUNTER_WORDS == 9, "the initialiser below follows DevCounters word for word");
     const int ws = wave_sum(tc.sph), wp = wave_sum(tc.pl), wt = wave_sum(tc.tri), we = wave_sum(tc.exact),
-              wsh = wave_sum(tc.shadow);
-    // the filter counts are the same in every lane of the wave
+              wsh = wave_sum(tc.shadow), wg = wave_sum(tc.grid);
+    // the filter counts are the same in every lane of the wave; the cells of grid walks count with them
     const unsigned long long v[COUNTER_WORDS] = {(unsigned long long)ws, (unsigned long long)wp, (unsigned long long)wt,
-                                                 (unsigned long long)we, 64ull * (unsigned long long)tc.filt_rays,
+                                                 (unsigned long long)we,
+                                                 64ull * (unsigned long long)tc.filt_rays + (unsigned long long)wg,
                                                  64ull * (unsigned long long)tc.filt_terms, 0ull, 0ull,
                                                  (unsigned long long)wsh};
     flush_counters(f, cnt_sh, v);
@@ -2181,6 +2183,330 @@ __global__ void __launch_bounds__(256) k_reflect_finish(DevScene s, DevFrame f, 
         const f3 rh[1] = {hit2}, rd[1] = {r.dir};
         push_records<1, false>(f, s, level + 1, blk, rv, rp, rh, rd, rparent);
     }
+    if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
+}
+
+// ---------------------------------------------------------------------------------------
+// Grid walk: the closest sphere along a reflection ray from the spheres' uniform grid (rt_device.h,
+// DevScene::gr_*; built, and proven to list every sphere the reference can accept, in rt_api.cpp,
+// build_sphere_grid).  One ray per lane: the cells along the ray are visited nearest first
+// (three-dimensional DDA in cell coordinates; the exit parameter of a cell is recomputed from the
+// plane's index at every step, so no error accumulates), Sphere.Intersect runs over each visited
+// cell's list, and the walk stops when the closest hit so far - planes and triangles were offered
+// before the walk - lies before the parameter at which the ray leaves the cell.  A sphere listed in
+// several cells is met several times, which changes nothing: the result is the lexicographic
+// minimum of (t, host index) over everything evaluated, exactly what Scene.Intersect's scan with its
+// strict `<` keeps (MyApplication.cs:352-368).  Entries are loaded two at a time without looking
+// at the list's end: lists start at even entries, and what follows a list is never-hit padding or
+// another cell's spheres, and evaluating more spheres cannot change the result either.
+//
+// Rays are uneven (one meets a sphere in its first cell, its neighbour crosses the room), and a
+// wave pays for its slowest lane, so two things keep the lanes busy:
+//   * A workgroup takes a tile of up to GRID_TILE_MAX records and its lanes take rays from it as
+//     they become free (a wave refills when half its lanes are idle); the results meet in LDS and
+//     are pushed as the next level's records together, one counter atomic per tile.
+//   * The IEEE square root and divide of Sphere.Intersect (~60 instructions, executed by a wave
+//     whenever ANY lane has a candidate) are put off: a candidate's t is first bracketed with the
+//     one-ulp hardware square root and reciprocal,
+//         t_a = (-b - sqrt~(disc)) * rcp~(2a),   |t - t_a| <= delta = 1e-6 (|b| + sqrt~(disc) + |t_a|) + 1e-18
+//     (t = the reference's own FP32 result: both evaluations share b, disc and 2a; the two square
+//     roots differ by <= 3u sqrt(disc), the two subtractions round once each, <= 2u (|b| + sqrt),
+//     the quotients by <= 4u |t|, u = 2^-24; 1e-18 covers an operand the hardware flushes to
+//     zero), and the lane keeps ONE closest candidate as [lo, hi]: a new one with lo > hi_kept is
+//     strictly farther and dropped, one with hi < lo_kept replaces it, and only brackets that
+//     overlap (or straddle the epsilon of MyApplication.cs:359) are resolved with the literal
+//     evaluation on the spot.  The kept candidate gets its literal evaluation once, when the lane's
+//     walk is over, together with the other lanes that finished since the last refill.
+// Origins outside the region the lists were built for evaluate every sphere of the scene.
+// ---------------------------------------------------------------------------------------
+#define GRID_TILE_MAX 512
+#ifndef GRID_REFILL_BELOW
+#define GRID_REFILL_BELOW 32
+#endif
+struct GridLds {
+    float t[GRID_TILE_MAX];       // per record of the tile: the closest hit's t,
+    int prim[GRID_TILE_MAX];      //   its host index (INT_MAX: none),
+    float dx[GRID_TILE_MAX], dy[GRID_TILE_MAX], dz[GRID_TILE_MAX];   // and the mirror direction
+    unsigned next;                // records of the tile handed out so far
+};
+
+// Sphere.Intersect objects.cs:112-121, literally; false: no hit the reference accepts.
+__device__ __forceinline__ bool grid_exact(const float4 sp, const f3 o, const f3 d, const float a, float &t)
+{
+    const f3 op = sub3(o, xyz(sp));
+    const float c = dot3(op, op) - sp.w;
+    const float x = dot3(d, op);
+    return sphere_maybe(x, a * c) && sphere_root(x, c, a, t) && t > RT_EPS;
+}
+
+// The closest candidate of a lane: [lo, hi] brackets the reference's t; e >= 0: entry of gr_sph whose
+// literal evaluation is still owed, e < 0: lo = hi = the literal t (or nothing yet: prim = INT_MAX).
+struct GridBest {
+    float lo, hi;
+    int prim, e;
+};
+
+__device__ __forceinline__ void grid_candidate(const DevScene &s, const float4 sp, const int orig, const unsigned e,
+                                               const f3 o, const f3 d, const float a, GridBest &b)
+{
+    const f3 op = sub3(o, xyz(sp));
+    const float c = dot3(op, op) - sp.w;
+    const float x = dot3(d, op);
+    if (!sphere_maybe(x, a * c)) return;
+    const float bb = 2.0f * x;
+    const float disc = (bb * bb) - ((4.0f * a) * c);   // (as sphere_root forms it)
+    if (disc < 0.0f) return;
+    const float sq = __builtin_amdgcn_sqrtf(disc);
+    const float ta = ((-bb) - sq) * __builtin_amdgcn_rcpf(2.0f * a);
+    const float delta = 1e-6f * ((fabsf(bb) + sq) + fabsf(ta)) + 1e-18f;
+    const float lo = ta - delta, hi = ta + delta;
+    if (hi <= RT_EPS || lo > b.hi || orig == b.prim) return;   // not a hit, strictly farther, or met before
+    if (lo > RT_EPS && hi < b.lo) {   // strictly closer
+        b.lo = lo, b.hi = hi, b.prim = orig, b.e = (int)e;
+        return;
+    }
+    // The brackets overlap (or one straddles epsilon): the literal evaluation decides.
+    if (b.e >= 0) {
+        const float4 kept = s.gr_sph[b.e];
+        const f3 kp = sub3(o, xyz(kept));
+        float tk = b.lo;
+        (void)sphere_root(dot3(d, kp), dot3(kp, kp) - kept.w, a, tk);   // (a hit: its bracket lies above epsilon)
+        b.lo = b.hi = tk;
+        b.e = -1;
+    }
+    float t;
+    if (sphere_root(x, c, a, t) && t > RT_EPS && (t < b.lo || (t == b.lo && orig < b.prim)))
+        b.lo = b.hi = t, b.prim = orig, b.e = -1;
+}
+
+// One axis of the ray in cell coordinates: where the ray is inside the grid's slab.
+__device__ __forceinline__ void grid_slab(const float g, const float dg, const float r, const float n, float &tn, float &tf)
+{
+    const float ta = (0.0f - g) * r, tb = (n - g) * r;
+    tn = fminf(ta, tb);
+    tf = fmaxf(ta, tb);
+    if (dg == 0.0f) {
+        const bool in = g >= 0.0f && g <= n;
+        tn = in ? -RT_FLT_MAX : RT_FLT_MAX;
+        tf = in ? RT_FLT_MAX : -RT_FLT_MAX;
+    }
+}
+
+#define GRID_EMPTY 0      // the lane has no ray
+#define GRID_WALKING 1
+#define GRID_FINISHED 2   // the walk is over, the kept candidate's literal evaluation and the result are owed
+
+// The reflection rays of records [first, first + count) of a level's reflecting queue, count <= GRID_TILE_MAX,
+// and the next level's records they create.  Every thread of the workgroup must call it.
+// THROUGH: the records are read and written within one launch by several XCDs (k_trace_levels); otherwise
+// a launch per level.
+template <bool COUNT, bool THROUGH>
+__device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const DevFrame &f, GridLds &G, int *blk,
+                                                     const int level, const int first, const int count, TestCount &tc)
+{
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) G.next = 0u;
+    __syncthreads();
+    const int n0 = s.gr_n[0], n1 = s.gr_n[1], n2 = s.gr_n[2];
+    int state = GRID_EMPTY, my = 0, left = 0, cell = 0;
+    unsigned e = 0u, end = 0u;
+    f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
+    float a = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f, tmx = 0.f, tmy = 0.f, tmz = 0.f;
+    GridBest best = {RT_FLT_MAX, RT_FLT_MAX, INT_MAX, -1};
+    bool exhausted = false;
+    int cells = 0, tests = 0;
+    for (;;) {
+        const int walking = __popcll(__ballot(state == GRID_WALKING));
+        // Refill when half the lanes are idle; once the tile has no rays left, settle the finished lanes
+        // together when the last walk is over.
+        if (exhausted ? (walking == 0 && __any(state == GRID_FINISHED)) : walking <= GRID_REFILL_BELOW) {
+            // ---- results of the lanes that finished since the last refill ----
+            if (state == GRID_FINISHED) {
+                float t = best.lo;
+                if (best.e >= 0) {
+                    const float4 sp = s.gr_sph[best.e];
+                    const f3 op = sub3(o, xyz(sp));
+                    (void)sphere_root(dot3(d, op), dot3(op, op) - sp.w, a, t);   // (a hit: its bracket lies above epsilon)
+                }
+                G.t[my] = t;
+                G.prim[my] = best.prim;
+                G.dx[my] = d.x, G.dy[my] = d.y, G.dz[my] = d.z;
+                state = GRID_EMPTY;
+            }
+            // ---- new rays for the idle lanes ----
+            if (!exhausted) {
+                const unsigned long long idle = __ballot(state == GRID_EMPTY);
+                unsigned base = 0u;
+                if (lane == 0) base = atomicAdd(&G.next, (unsigned)__popcll(idle));
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                exhausted = base + (unsigned)__popcll(idle) >= (unsigned)count;
+                const int mine = (int)base + __popcll(idle & ((1ull << lane) - 1ull));
+                if (state == GRID_EMPTY && mine < count) {
+                    my = mine;
+                    const int slot = level * f.P + first + my;
+                    float4 ra, rb;
+                    if (THROUGH) load_record(&f.recA[slot], &f.recB[slot], ra, rb);
+                    else ra = f.recA[slot], rb = f.recB[slot];
+                    o = xyz(ra);
+                    const f3 view = xyz(rb);
+                    const int prim = __float_as_int(ra.w);
+                    const int type = __float_as_int(cload(s.mat, 3 * prim + 1).w) & RT_MF_TYPE_MASK;
+                    const f3 normal = record_normal(s, prim, type, o);
+                    // objects.cs:82: (viewDir - 2 * Dot(viewDir, normal) * normal).Normalized()
+                    d = normalized3(sub3(view, scale3(normal, 2.0f * dot3(view, normal))));
+                    a = dot3(d, d);
+                    Closest sec = {RT_FLT_MAX, INT_MAX};
+                    for (int j = 0; j < s.np; j++) {
+                        const float4 pl = cload(s.pl, j);
+                        const f3 nn = xyz(pl);
+                        float t;
+                        if (plane_t(nn, (-dot3(nn, o)) - pl.w, d, t)) closest_offer(sec, t, cload(s.pl_orig, j));
+                    }
+                    for (int j = 0; j < s.nt; j++) {
+                        const f3 v0 = xyz(cload(s.tri, 3 * j)), e1 = xyz(cload(s.tri, 3 * j + 1)), e2 = xyz(cload(s.tri, 3 * j + 2));
+                        float t;
+                        if (triangle_t(e1, e2, sub3(o, v0), d, t)) closest_offer(sec, t, cload(s.tri_orig, j));
+                    }
+                    best.lo = best.hi = sec.t, best.prim = sec.prim, best.e = -1;
+                    state = GRID_FINISHED;   // unless the walk below starts
+                    const bool served = o.x >= s.gr_reg_lo[0] && o.x <= s.gr_reg_hi[0] && o.y >= s.gr_reg_lo[1] &&
+                                        o.y <= s.gr_reg_hi[1] && o.z >= s.gr_reg_lo[2] && o.z <= s.gr_reg_hi[2];
+                    if (!served) {
+                        // An origin the lists were not built for: every sphere of the scene.
+                        for (int i = 0; i < s.ns_padded; i++) {
+                            float t;
+                            if (grid_exact(s.sph[i], o, d, a, t)) {
+                                const int orig = s.sph_orig[i];
+                                if (t < best.lo || (t == best.lo && orig < best.prim)) best.lo = best.hi = t, best.prim = orig;
+                            }
+                        }
+                        tests += s.ns_padded;
+                    } else {
+                        // The ray in cell coordinates and where it is inside the grid.
+                        gx = (o.x - s.gr_lo[0]) * s.gr_ih[0], gy = (o.y - s.gr_lo[1]) * s.gr_ih[1], gz = (o.z - s.gr_lo[2]) * s.gr_ih[2];
+                        const float ddx = d.x * s.gr_ih[0], ddy = d.y * s.gr_ih[1], ddz = d.z * s.gr_ih[2];
+                        // (a zero component: its reciprocal is an infinity of the direction's sign, which the
+                        // slab test and the exit parameters below treat as "never crossed")
+                        rx = __builtin_amdgcn_rcpf(ddx), ry = __builtin_amdgcn_rcpf(ddy), rz = __builtin_amdgcn_rcpf(ddz);
+                        float tnx, tfx, tny, tfy, tnz, tfz;
+                        grid_slab(gx, ddx, rx, (float)n0, tnx, tfx);
+                        grid_slab(gy, ddy, ry, (float)n1, tny, tfy);
+                        grid_slab(gz, ddz, rz, (float)n2, tnz, tfz);
+                        const float t_in = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f)), t_out = fminf(fminf(tfx, tfy), tfz);
+                        if (t_in <= t_out && !(best.hi < t_in)) {   // the ray meets the grid before its closest hit so far
+                            const int ix = min(max((int)floorf(gx + t_in * ddx), 0), n0 - 1),
+                                      iy = min(max((int)floorf(gy + t_in * ddy), 0), n1 - 1),
+                                      iz = min(max((int)floorf(gz + t_in * ddz), 0), n2 - 1);
+                            cell = ix | (iy << 10) | (iz << 20);
+                            // parameter at which the ray leaves the current cell along each axis
+                            tmx = ddx == 0.0f ? RT_FLT_MAX : ((float)(ix + (rx > 0.0f ? 1 : 0)) - gx) * rx;
+                            tmy = ddy == 0.0f ? RT_FLT_MAX : ((float)(iy + (ry > 0.0f ? 1 : 0)) - gy) * ry;
+                            tmz = ddz == 0.0f ? RT_FLT_MAX : ((float)(iz + (rz > 0.0f ? 1 : 0)) - gz) * rz;
+                            const uint2 cur = s.gr_cells[(iz * n1 + iy) * n0 + ix];
+                            e = cur.x, end = cur.x + cur.y;
+                            left = n0 + n1 + n2 + 3;   // (a ray of NaNs must end too)
+                            cells++;
+                            state = GRID_WALKING;
+                        }
+                    }
+                }
+            }
+        }
+        if (!__any(state == GRID_WALKING)) {
+            if (exhausted && !__any(state == GRID_FINISHED)) break;   // nothing left in the tile for this wave
+            continue;
+        }
+        // ---- one step of every walking lane: two entries of its cell, then on to the next cell ----
+        if (state == GRID_WALKING) {
+            if (e < end) {
+                const float4 s0 = s.gr_sph[e], s1 = s.gr_sph[e + 1];
+                const int2 og = *reinterpret_cast<const int2 *>(&s.gr_orig[e]);
+                grid_candidate(s, s0, og.x, e, o, d, a, best);
+                grid_candidate(s, s1, og.y, e + 1u, o, d, a, best);
+                e += 2u;
+                tests += 2;
+            }
+            if (e >= end) {
+                const float leave = fminf(fminf(tmx, tmy), tmz);
+                const bool bx = tmx <= tmy && tmx <= tmz, by = !bx && tmy <= tmz;
+                int ix = cell & 1023, iy = (cell >> 10) & 1023, iz = cell >> 20;
+                if (bx) ix += rx > 0.0f ? 1 : -1;
+                else if (by) iy += ry > 0.0f ? 1 : -1;
+                else iz += rz > 0.0f ? 1 : -1;
+                const bool inside = (unsigned)ix < (unsigned)n0 && (unsigned)iy < (unsigned)n1 && (unsigned)iz < (unsigned)n2;
+                if (best.hi < leave || !inside || --left <= 0) {
+                    state = GRID_FINISHED;
+                } else {
+                    cell = ix | (iy << 10) | (iz << 20);
+                    const uint2 cur = s.gr_cells[(iz * n1 + iy) * n0 + ix];
+                    e = cur.x, end = cur.x + cur.y;
+                    if (bx) tmx = ((float)(ix + (rx > 0.0f ? 1 : 0)) - gx) * rx;
+                    else if (by) tmy = ((float)(iy + (ry > 0.0f ? 1 : 0)) - gy) * ry;
+                    else tmz = ((float)(iz + (rz > 0.0f ? 1 : 0)) - gz) * rz;
+                    cells++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the next level's records ----
+    constexpr int PER = GRID_TILE_MAX / 256;
+    bool rv[PER];
+    int rp[PER], rparent[PER];
+    f3 rh[PER], rd[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int j = k * 256 + (int)threadIdx.x;
+        const bool active = j < count;
+        const int jj = active ? j : 0;
+        const int slot = level * f.P + first + jj;
+        const int hit_prim = G.prim[jj];
+        const float t = G.t[jj];
+        rd[k] = mk3(G.dx[jj], G.dy[jj], G.dz[jj]);
+        f3 hit = mk3(0.f, 0.f, 0.f);
+        if (active) {
+            float4 ra, rb;
+            if (THROUGH) load_record(&f.recA[slot], &f.recB[slot], ra, rb);
+            else ra = f.recA[slot];
+            hit = xyz(ra);
+            // no reflected colour yet (see reflection_tile for the store's form)
+            if (THROUGH) store_record(&f.refl[slot], f4raw{0.0f, 0.0f, 0.0f, 0.0f});
+            else f.refl[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        rv[k] = active && hit_prim != INT_MAX;
+        rp[k] = rv[k] ? hit_prim : 0;
+        rparent[k] = slot;
+        rh[k] = add3(hit, scale3(rd[k], t));   // objects.cs:123,166,263
+        if (COUNT && active) {
+            tc.sph += s.ns;
+            tc.pl += s.np;
+            tc.tri += s.nt;
+        }
+    }
+    if (COUNT) {
+        tc.exact += tests;
+        tc.grid += cells;
+    }
+    push_records<PER, THROUGH>(f, s, level + 1, blk, rv, rp, rh, rd, rparent);
+}
+
+#ifndef RT_GRID_WAVES
+#define RT_GRID_WAVES 6
+#endif
+template <bool COUNT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GRID_WAVES)))
+k_reflect_grid(DevScene s, DevFrame f, int level)
+{
+    __shared__ GridLds G;
+    __shared__ int blk[12];
+    __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
+    const int n = f.cnt[2 * level];
+    // Large levels: GRID_TILE_MAX records per tile (half as many contended counter atomics); small ones: 256, so
+    // that more workgroups share the level.
+    const int per_tile = n >= GRID_TILE_MAX * (int)gridDim.x ? GRID_TILE_MAX : 256;
+    TestCount tc = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long first = (long long)blockIdx.x * per_tile; first < n; first += (long long)gridDim.x * per_tile)
+        reflection_tile_grid<COUNT, false>(s, f, G, blk, level, (int)first, min(per_tile, n - (int)first), tc);
     if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
 }
 
@@ -2435,11 +2761,13 @@ struct Taker {
 // large frame in register pressure.
 // COUNT: the work counters of rt_stats are kept (profiling); without them the compiler drops
 // the per-lane sums and the per-light prefix lookups they are made of.
-template <bool MULTI, bool RESERVE, bool COUNT>
+// GRID: the reflection rays walk the spheres' grid (reflection_tile_grid) instead of the staged scene.
+template <bool MULTI, bool RESERVE, bool COUNT, bool GRID = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 k_trace_levels(DevScene s, DevFrame f, int32_t *pixels)
 {
     __shared__ WalkLds L;
+    __shared__ GridLds G;   // (only one of the two is used, and only that one allocated)
     __shared__ int blk[12];
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     __shared__ int job[4];
@@ -2544,14 +2872,17 @@ k_trace_levels(DevScene s, DevFrame f, int32_t *pixels)
         const int kind = job[0], lvl = job[1], tile = job[2], n = job[3];
         if (kind == SCHED_JOB_EXIT) break;
         // Only reflection rays walk the staged spheres: stage them before the first such tile.
-        if (!MULTI && !staged && kind == SCHED_JOB_A) {
-            stage_chunk(L, s, 0, s.ns_padded);
-            staged = true;
+        if constexpr (!GRID) {
+            if (!MULTI && !staged && kind == SCHED_JOB_A) {
+                stage_chunk(L, s, 0, s.ns_padded);
+                staged = true;
+            }
         }
         __syncthreads();   // job[] read by all, spheres staged
         if (kind == SCHED_JOB_A) {
             __builtin_amdgcn_s_setprio(3);   // the chain of levels is the launch's critical path
-            reflection_tile<MULTI>(s, f, L, blk, lvl, tile, n, tc, pc);
+            if constexpr (GRID) reflection_tile_grid<COUNT, true>(s, f, G, blk, lvl, tile * 256, min(256, n - tile * 256), tc);
+            else reflection_tile<MULTI>(s, f, L, blk, lvl, tile, n, tc, pc);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's record stores have reached memory
             __builtin_amdgcn_s_setprio(0);
             __syncthreads();
@@ -2832,6 +3163,9 @@ void rtk_trace(const DevScene &s, const DevFrame &f, int level, bool reflecting,
     if (!reflecting) {
         if (count) hipLaunchKernelGGL(k_plain<true>, g, b, 0, stream, s, f, level, pixels);
         else hipLaunchKernelGGL(k_plain<false>, g, b, 0, stream, s, f, level, pixels);
+    } else if (s.gr_n[0] > 0) {
+        if (count) hipLaunchKernelGGL(k_reflect_grid<true>, g, b, 0, stream, s, f, level);
+        else hipLaunchKernelGGL(k_reflect_grid<false>, g, b, 0, stream, s, f, level);
     } else if (multi_chunk(s)) {
         if (count) hipLaunchKernelGGL((k_reflect<true, true>), g, b, 0, stream, s, f, level);
         else hipLaunchKernelGGL((k_reflect<true, false>), g, b, 0, stream, s, f, level);
@@ -2866,6 +3200,7 @@ typedef void (*trace_levels_kernel)(DevScene, DevFrame, int32_t *);
 template <bool RESERVE, bool COUNT>
 static trace_levels_kernel trace_levels_pick(const DevScene &s)
 {
+    if (s.gr_n[0] > 0) return k_trace_levels<false, RESERVE, COUNT, true>;
     return multi_chunk(s) ? k_trace_levels<true, RESERVE, COUNT> : k_trace_levels<false, RESERVE, COUNT>;
 }
 static trace_levels_kernel trace_levels_for(const DevScene &s, bool reserve = false, bool count = true)

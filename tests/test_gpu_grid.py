@@ -1,0 +1,90 @@
+"""The reflection rays' walk through the spheres' uniform grid (k_reflect_grid) against the CPU
+restatement and against the kernels that walk the LDS-staged scene: the grid only selects which
+spheres get the literal Sphere.Intersect, so every frame must be identical with it, without it, at
+any resolution of the grid, and whatever part of the scene the grid's lists were built to serve."""
+import numpy as np
+import pytest
+
+from raytracer_amd import Camera, Light, Material, Plane, RenderContext, Scene, Sphere, scene_1k, scene_64k, synthetic_scene
+
+pytestmark = pytest.mark.gpu
+
+
+_oracle_frames = {}   # the CPU restatement's frames, rendered once per (scene name, frame)
+
+
+def frames_equal_oracle(oracle, fs, cam, w, h, depth, what, row_step=1, key=None):
+    with RenderContext() as c:
+        c.set_profiling(True)   # the Intersect-call counters are compared too
+        c.set_scene(fs)
+        gpu = c.render(cam, w, h, depth)
+        st = c.stats()
+    if key is None or key not in _oracle_frames:
+        _oracle_frames[key] = oracle.render(fs, cam, w, h, max_depth=depth, row_step=row_step)
+    ref, cnt = _oracle_frames[key]
+    rows = list(range(0, h, row_step))
+    bad = np.argwhere(gpu[rows] != ref[rows])
+    assert bad.size == 0, f"{what}: {len(bad)} pixels differ, first at {tuple(bad[0])}"
+    if row_step == 1:
+        for k in ("rays_shadow", "rays_secondary", "shaded_hits", "sphere_tests", "plane_tests", "triangle_tests"):
+            assert st[k] == cnt[k], (what, k, st[k], cnt[k])
+    return gpu
+
+
+@pytest.mark.parametrize("knob,value", [("RT_HIP_GRID", "0"), ("RT_HIP_GRID_DENSITY", "0.05"), ("RT_HIP_GRID_DENSITY", "64"),
+                                        ("RT_HIP_GRID_REGION", "0"), ("RT_HIP_GRID_REGION", "8")])
+def test_any_grid_gives_the_same_frame(oracle, monkeypatch, knob, value):
+    """No grid at all, one cell per twenty spheres, 64 cells per sphere, a served region that ends at
+    the spheres' own extent (most reflection rays then start outside it and evaluate every sphere, in
+    the same waves as rays that walk the grid), one that reaches far beyond the room."""
+    cam = Camera(position=(0.3, -0.4, -0.5), direction=(0.1, -0.05, 1.0))
+    fs1, fs64 = scene_1k().flatten(), scene_64k().flatten()
+    base1 = frames_equal_oracle(oracle, fs1, cam, 256, 144, 4, "1k spheres, default grid", key="1k")
+    base64 = frames_equal_oracle(oracle, fs64, Camera(), 96, 54, 8, "64k spheres, default grid", key="64k")
+    monkeypatch.setenv(knob, value)
+    assert np.array_equal(base1, frames_equal_oracle(oracle, fs1, cam, 256, 144, 4, f"1k spheres, {knob}={value}", key="1k"))
+    assert np.array_equal(base64, frames_equal_oracle(oracle, fs64, Camera(), 96, 54, 8, f"64k spheres, {knob}={value}", key="64k"))
+
+
+def test_axis_parallel_reflection_rays(oracle):
+    """A mirror wall seen head-on: the centre column's and row's reflection rays have one or two
+    direction components that are exactly zero (reciprocals of zero in the walk), and they come back
+    through a lattice of spheres whose centres lie exactly on cell-aligned coordinates."""
+    s = Scene()
+    mirror = Material(0.0, specular=1.0, ambientColor=(0, 0, 0, 1), diffuseColor=(0, 0, 0, 1))
+    s.Add(Plane(0.0, 0.0, -1.0, 6.0, mirror))                      # z = 6, faces the camera
+    s.Add(Plane(0.0, 0.0, 1.0, 3.0, Material(1.0, ambientColor=(0.2, 0.1, 0.1, 1.0))))   # z = -3, behind it
+    for k in range(5):
+        for j in range(5):
+            for i in range(5):
+                if (i, j) == (2, 2) and k < 4:
+                    continue   # a clear line of sight along the axis, up to the last layer
+                s.Add(Sphere(-1.0 + 0.5 * i, -1.0 + 0.5 * j, 1.0 + 0.5 * k, 0.125 + 0.01 * ((i + j + k) % 3),
+                             mirror if (i + j + k) % 4 == 0 else Material(1.0)))
+    s.Add(Light(0.0, -3.0, 0.0))
+    s.Add(Light(2.0, 1.0, -1.0))
+    fs = s.flatten()
+    for cam in (Camera(position=(0.0, 0.0, -2.0), direction=(0.0, 0.0, 1.0), fov=50.0),
+                Camera(position=(0.0, 0.0, 8.5), direction=(0.0, 0.0, -1.0), fov=70.0),      # from behind the mirror's plane
+                Camera(position=(-3.0, 0.0, 2.0), direction=(1.0, 0.0, 0.0), fov=40.0)):     # along x through the lattice
+        frames_equal_oracle(oracle, fs, cam, 129, 97, 5, f"lattice from {cam.position}")
+
+
+def test_grid_on_the_full_size_frame(oracle):
+    """3840x2160: the first level holds more than a million reflection rays, which takes the tiles of 512
+    records; every 120th row against the CPU restatement."""
+    frames_equal_oracle(oracle, scene_1k().flatten(), Camera(), 3840, 2160, 4, "1k spheres at 4K", row_step=120)
+
+
+def test_clustered_spheres_and_an_outlier(oracle):
+    """Two tight clusters and one sphere far away: the grid's extent is set by the outlier, nearly all
+    spheres share a handful of cells, and the rays cross long stretches of empty cells."""
+    s = synthetic_scene(0)
+    rng = np.random.default_rng(11)
+    mirror = Material(0.0, specular=1.0, ambientColor=(0, 0, 0, 1), diffuseColor=(0, 0, 0, 1))
+    for cx, cz in ((-1.5, 2.0), (1.8, 2.8)):
+        for i in range(150):
+            p = rng.normal(0.0, 0.25, 3)
+            s.Add(Sphere(cx + p[0], -1.0 + p[1], cz + p[2], float(rng.uniform(0.01, 0.06)), mirror if i % 2 else Material(1.0)))
+    s.Add(Sphere(300.0, -200.0, 900.0, 40.0, Material(1.0)))
+    frames_equal_oracle(oracle, s.flatten(), Camera(), 192, 108, 5, "clusters and an outlier")
