@@ -760,7 +760,7 @@ void build_light_tables(PackedScene &out)
 // No grid (the kernels that walk the LDS-staged scene are used): fewer than RT_GRID_MIN_SPHERES usable
 // spheres, extents that are not finite, or lists that would grow out of proportion (a sphere that
 // covers thousands of cells).  RT_HIP_GRID=0 (tuning aid) turns it off; RT_HIP_GRID_DENSITY = cells
-// per sphere (default 4); RT_HIP_GRID_REGION = how far the served region reaches beyond the spheres'
+// per sphere (default 2); RT_HIP_GRID_REGION = how far the served region reaches beyond the spheres'
 // extent, in units of its largest side (default 0.5).
 // ---------------------------------------------------------------------------------------
 constexpr size_t RT_GRID_MIN_SPHERES = 64;
@@ -776,7 +776,7 @@ void build_sphere_grid(PackedScene &out)
     const char *env = getenv("RT_HIP_GRID");
     if (env && atoi(env) == 0) return;
     const char *dens_env = getenv("RT_HIP_GRID_DENSITY"), *reg_env = getenv("RT_HIP_GRID_REGION");
-    const double density = dens_env && atof(dens_env) > 0.0 ? atof(dens_env) : 4.0;
+    const double density = dens_env && atof(dens_env) > 0.0 ? atof(dens_env) : 2.0;
     const double reach = reg_env && atof(reg_env) >= 0.0 ? atof(reg_env) : 0.5;
     const double u24 = 1.0 / 16777216.0;
     std::vector<uint32_t> use;
@@ -854,10 +854,29 @@ void build_sphere_grid(PackedScene &out)
     if (total > 64 * use.size() + 4096 || total >= ((size_t)1 << 30)) return;
     out.gr_cells.assign(ncells, uint2{0u, 0u});
     auto cell_of = [&](int x, int y, int z) { return ((size_t)z * n[1] + y) * n[0] + x; };
-    for (const Range &r : ranges)
+    // Of the cells its box covers a sphere is listed in those that come within R (+ the walk's GRID_EPS cells, as
+    // a distance) of its centre: the corners of the box do not.
+    double eps_len = 0.0;
+    for (int k = 0; k < 3; k++) eps_len = std::max(eps_len, GRID_EPS / (double)ih_f[k]);
+    eps_len *= 1.7321;
+    auto for_cells = [&](size_t j, auto &&visit) {
+        const Range &r = ranges[j];
+        const float4 &sp = out.sph[use[j]];
+        const double R = widened(sp) + eps_len, c[3] = {sp.x, sp.y, sp.z};
+        double gap2[3][RT_GRID_MAX_AXIS];   // per axis and cell of the range: squared distance of the centre from the cell's slab
+        for (int k = 0; k < 3; k++)
+            for (int i = r.a[k]; i <= r.b[k]; i++) {
+                const double lo_i = (double)lo_f[k] + (double)i / (double)ih_f[k], hi_i = (double)lo_f[k] + (double)(i + 1) / (double)ih_f[k];
+                const double gap = c[k] < lo_i ? lo_i - c[k] : (c[k] > hi_i ? c[k] - hi_i : 0.0);
+                gap2[k][i] = gap * gap;
+            }
+        const double R2 = R * R * (1.0 + 1e-9);
         for (int z = r.a[2]; z <= r.b[2]; z++)
             for (int y = r.a[1]; y <= r.b[1]; y++)
-                for (int x = r.a[0]; x <= r.b[0]; x++) out.gr_cells[cell_of(x, y, z)].y++;
+                for (int x = r.a[0]; x <= r.b[0]; x++)
+                    if (gap2[0][x] + gap2[1][y] + gap2[2][z] <= R2) visit(out.gr_cells[cell_of(x, y, z)]);
+    };
+    for (size_t j = 0; j < use.size(); j++) for_cells(j, [](uint2 &c) { c.y++; });
     // Every list starts at an even entry (the kernel loads its entries in pairs); the gaps and the
     // arrays' ends hold entries that can never be hit.
     size_t off = 0;
@@ -872,17 +891,12 @@ void build_sphere_grid(PackedScene &out)
     }
     out.gr_sph.assign(off + RT_GRID_PAD, float4{0.f, 0.f, 0.f, -INFINITY});
     out.gr_orig.assign(off + RT_GRID_PAD, INT32_MAX);
-    for (size_t j = 0; j < use.size(); j++) {
-        const Range &r = ranges[j];
-        for (int z = r.a[2]; z <= r.b[2]; z++)
-            for (int y = r.a[1]; y <= r.b[1]; y++)
-                for (int x = r.a[0]; x <= r.b[0]; x++) {
-                    uint2 &c = out.gr_cells[cell_of(x, y, z)];
-                    out.gr_sph[(size_t)c.x + c.y] = out.sph[use[j]];
-                    out.gr_orig[(size_t)c.x + c.y] = out.sph_orig[use[j]];
-                    c.y++;
-                }
-    }
+    for (size_t j = 0; j < use.size(); j++)
+        for_cells(j, [&](uint2 &c) {
+            out.gr_sph[(size_t)c.x + c.y] = out.sph[use[j]];
+            out.gr_orig[(size_t)c.x + c.y] = out.sph_orig[use[j]];
+            c.y++;
+        });
     for (int k = 0; k < 3; k++) {
         out.gr_n[k] = n[k];
         out.gr_lo[k] = lo_f[k];

@@ -1428,14 +1428,28 @@ __device__ __forceinline__ uint2 light_table_cell(const DevScene &s, const int l
     return s.lt_cells[((size_t)(l * 6 + face) * (size_t)s.lt_n + (size_t)iv) * (size_t)s.lt_n + (size_t)iu];
 }
 
-// One light ray against one sphere, objects.cs:112-121 literally; true = an occluder in (eps, dist).
+// One light ray against one sphere: true = Sphere.Intersect (objects.cs:112-121) gives a t in (eps, dist).
+// The IEEE square root and divide of the literal evaluation cost ~60 instructions, and a wave executes them
+// whenever ANY lane has a candidate, so the candidate's t is first bracketed with the one-ulp hardware
+// square root and reciprocal (the bracket and its bound: "Grid walk" below), which settles the answer
+// unless t lies within the bracket's width of one of the two bounds; only then is the literal evaluation
+// made (also for operands that are not finite: every comparison below is then false).
 __device__ __forceinline__ bool sphere_occludes(const float4 sp, const f3 o, const f3 d, const float a, const float dist)
 {
     const f3 op = sub3(o, xyz(sp));
     const float c = dot3(op, op) - sp.w;
     const float x = dot3(d, op);
+    if (!sphere_maybe(x, a * c)) return false;
+    const float bb = 2.0f * x;
+    const float disc = (bb * bb) - ((4.0f * a) * c);   // (as sphere_root forms it)
+    if (disc < 0.0f) return false;
+    const float sq = __builtin_amdgcn_sqrtf(disc);
+    const float ta = ((-bb) - sq) * __builtin_amdgcn_rcpf(2.0f * a);
+    const float delta = 1e-6f * ((fabsf(bb) + sq) + fabsf(ta)) + 1e-18f;
+    if (ta + delta <= RT_EPS || ta - delta >= dist) return false;
+    if (ta - delta > RT_EPS && ta + delta < dist) return true;
     float t;
-    return sphere_maybe(x, a * c) && sphere_root(x, c, a, t) && t > RT_EPS && t < dist;
+    return sphere_root(x, c, a, t) && t > RT_EPS && t < dist;
 }
 
 // Is the ray from `hit` towards light l (direction d, a = d.d, length dist) occluded?  Returns the
@@ -2417,6 +2431,9 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
             continue;
         }
         // ---- one step of every walking lane: two entries of its cell, then on to the next cell ----
+        // (Tried and dropped, each slower by 10-50 %: the next cell's list fetched one step ahead; several
+        // cells per step for the lanes that cross empty ones.  The loop is bound by the instructions it
+        // issues, not by the latency of its loads.)
         if (state == GRID_WALKING) {
             if (e < end) {
                 const float4 s0 = s.gr_sph[e], s1 = s.gr_sph[e + 1];

@@ -8,5 +8,5 @@ W=/tmp/lt_$3
 rm -rf "$W"
 RT_HIP_LIBRARY=$LIB RT_HIP_LEVEL_KERNELS=1 timeout -k 10 200 rocprofv3 --kernel-trace --output-format rocpd -d "$W" -- \
     python3 "$REPO/tools/one_frame.py" "$2" 3 > "$REPO/gpurun_out/lt_$3.log" 2>&1 || exit 1
-python3 "$REPO/tools/level_times.py" "$(find "$W" -name '*.db' | head -1)" 24 | grep -E "reflect|primary" > "$REPO/gpurun_out/lt_$3.txt"
+python3 "$REPO/tools/level_times.py" "$(find "$W" -name '*.db' | head -1)" 24 > "$REPO/gpurun_out/lt_$3.txt"
 echo "== $3"; cat "$REPO/gpurun_out/lt_$3.txt"
