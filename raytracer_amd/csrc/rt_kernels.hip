@@ -2697,7 +2697,7 @@ k_plain_tail(DevScene s, DevFrame f, int level, int level_hi, int32_t *pixels)
             const int ntiles = (n + 255) >> 8;
             for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) plain_tile<COUNT>(s, f, lv, tile, n, pixels, tc, pc);
         }
-        if (f.lit && lv < f.max_depth) {
+        if (f.lit && lv < f.max_depth && !(f.light_waves > 0 && f.cnt[2 * lv] < f.light_split_below)) {
             const int na = f.cnt[2 * lv];
             const int ntiles = (na + 255) >> 8;
             for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -2716,6 +2716,7 @@ k_lit(DevScene s, DevFrame f, int level)
 {
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int n = f.cnt[2 * level];
+    if (f.light_waves > 0 && n < f.light_split_below) return;   // k_shade_lights (reflecting = 2) takes this queue
     const int ntiles = (n + 255) >> 8;
     TestCount tc = {0, 0, 0, 0, 0, 0, 0};
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -2973,6 +2974,9 @@ __global__ void __launch_bounds__(64 * LIGHT_WAVES_MAX) k_shade_lights(DevScene 
 {
     __shared__ float terms[LIGHT_WAVES_MAX][6][64];
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
+    // reflecting = 2: the light terms of the reflecting records into DevFrame::lit, ahead of their children
+    // (what k_lit does for long queues); nothing is summed or stored elsewhere.
+    const bool ahead = reflecting == 2;
     const int n = f.cnt[2 * level + (reflecting ? 0 : 1)];
     if (!(n < f.light_split_below)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
@@ -2985,7 +2989,7 @@ __global__ void __launch_bounds__(64 * LIGHT_WAVES_MAX) k_shade_lights(DevScene 
         const int ii = active ? i : n - 1;
         const int slot = reflecting ? level * f.P + ii : (level + 1) * f.P - 1 - ii;
         const bool through = !reflecting;   // as k_plain and k_shade read and write their records
-        const ShadeRecord r = shade_setup(s, f, slot, active, reflecting != 0, through);
+        const ShadeRecord r = shade_setup(s, f, slot, active, reflecting == 1, through);
         f3 final = mk3(0.0f, 0.0f, 0.0f);
         for (int l0 = 0; l0 < nl; l0 += W) {
             const int l = l0 + wave;
@@ -2995,9 +2999,11 @@ __global__ void __launch_bounds__(64 * LIGHT_WAVES_MAX) k_shade_lights(DevScene 
                 f3 reflected, direct;
                 float d2;
                 light_terms<COUNT>(s, r, l, cell, active, tc, reflected, direct, d2);
+                if (ahead && active) f.lit[(size_t)slot * (size_t)nl + (size_t)l] = make_float4(direct.x, direct.y, direct.z, d2);
                 terms[wave][0][lane] = reflected.x, terms[wave][1][lane] = reflected.y, terms[wave][2][lane] = reflected.z;
                 terms[wave][3][lane] = direct.x, terms[wave][4][lane] = direct.y, terms[wave][5][lane] = direct.z;
             }
+            if (ahead) continue;   // (uniform over the workgroup)
             __syncthreads();
             if (wave == 0) {
                 const int m = min(W, nl - l0);
@@ -3008,7 +3014,7 @@ __global__ void __launch_bounds__(64 * LIGHT_WAVES_MAX) k_shade_lights(DevScene 
             }
             __syncthreads();
         }
-        if (wave == 0 && active) shade_store(f, level, r.parent, final, through, pixels);
+        if (wave == 0 && active && !ahead) shade_store(f, level, r.parent, final, through, pixels);
     }
     if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
 }
@@ -3257,12 +3263,12 @@ void rtk_lit_level(const DevScene &s, const DevFrame &f, int level, int grid_blo
     else hipLaunchKernelGGL(k_lit<false>, dim3(grid_blocks), dim3(256), 0, stream, s, f, level);
 }
 
-void rtk_shade_lights(const DevScene &s, const DevFrame &f, int level, bool reflecting, int32_t *pixels, int grid_blocks,
+void rtk_shade_lights(const DevScene &s, const DevFrame &f, int level, int queue, int32_t *pixels, int grid_blocks,
                       hipStream_t stream)
 {
     const dim3 g(grid_blocks), b(64 * f.light_waves);
-    if (f.any_hit == 0) hipLaunchKernelGGL(k_shade_lights<true>, g, b, 0, stream, s, f, level, reflecting ? 1 : 0, pixels);
-    else hipLaunchKernelGGL(k_shade_lights<false>, g, b, 0, stream, s, f, level, reflecting ? 1 : 0, pixels);
+    if (f.any_hit == 0) hipLaunchKernelGGL(k_shade_lights<true>, g, b, 0, stream, s, f, level, queue, pixels);
+    else hipLaunchKernelGGL(k_shade_lights<false>, g, b, 0, stream, s, f, level, queue, pixels);
 }
 
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,

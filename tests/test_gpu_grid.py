@@ -88,3 +88,29 @@ def test_clustered_spheres_and_an_outlier(oracle):
             s.Add(Sphere(cx + p[0], -1.0 + p[1], cz + p[2], float(rng.uniform(0.01, 0.06)), mirror if i % 2 else Material(1.0)))
     s.Add(Sphere(300.0, -200.0, 900.0, 40.0, Material(1.0)))
     frames_equal_oracle(oracle, s.flatten(), Camera(), 192, 108, 5, "clusters and an outlier")
+
+
+def test_light_terms_ahead_with_many_lights(oracle, monkeypatch):
+    """The reflecting records' light terms computed ahead of their children for up to 16 lights (the default
+    stops at four): long queues one record per lane, short ones with the lights spread over waves."""
+    monkeypatch.setenv("RT_HIP_EARLY_LIGHTS_MAX", "16")
+    monkeypatch.setenv("RT_HIP_PIPELINE", "levels")
+    for profiling in (1, 0):
+        with RenderContext() as c:
+            c.set_profiling(profiling)
+            for fs, cam, w, h, depth, key in ((scene_64k().flatten(), Camera(), 96, 54, 8, "64k"),):
+                c.set_scene(fs)
+                gpu = c.render(cam, w, h, depth)
+                if key not in _oracle_frames:
+                    _oracle_frames[key] = oracle.render(fs, cam, w, h, max_depth=depth)
+                assert np.array_equal(gpu, _oracle_frames[key][0]), f"64k spheres, profiling {profiling}"
+            s = synthetic_scene(300, radius=(0.05, 0.3), seed=5)
+            s.lights.clear()
+            for i in range(9):
+                s.Add(Light(-2.0 + 0.5 * i, -3.0 + 0.3 * i, 0.5 + 0.3 * i))
+            fs = s.flatten()
+            c.set_scene(fs)
+            gpu = c.render(Camera(), 640, 360, 4)     # level 0 is a long queue, the deep levels short ones
+            ref, _ = oracle.render(fs, Camera(), 640, 360, max_depth=4, row_step=24)
+            rows = list(range(0, 360, 24))
+            assert np.array_equal(gpu[rows], ref[rows]), f"9 lights, profiling {profiling}"
