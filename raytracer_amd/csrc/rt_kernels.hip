@@ -2432,8 +2432,9 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
         }
         // ---- one step of every walking lane: two entries of its cell, then on to the next cell ----
         // (Tried and dropped, each slower by 10-50 %: the next cell's list fetched one step ahead; several
-        // cells per step for the lanes that cross empty ones.  The loop is bound by the instructions it
-        // issues, not by the latency of its loads.)
+        // cells per step for the lanes that cross empty ones; a 64-byte block per cell holding its first two
+        // spheres, so that moving on and testing is one fetch - empty cells then cost two tests each.  The
+        // loop is bound by the instructions it issues, not by the latency of its loads.)
         if (state == GRID_WALKING) {
             if (e < end) {
                 const float4 s0 = s.gr_sph[e], s1 = s.gr_sph[e + 1];

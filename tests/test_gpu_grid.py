@@ -10,6 +10,12 @@ from raytracer_amd import Camera, Light, Material, Plane, RenderContext, Scene, 
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def grid_for_every_scene(monkeypatch):
+    """By itself the library builds the grid only for scenes of more than 1024 spheres."""
+    monkeypatch.setenv("RT_HIP_GRID", "2")
+
+
 _oracle_frames = {}   # the CPU restatement's frames, rendered once per (scene name, frame)
 
 
@@ -114,3 +120,23 @@ def test_light_terms_ahead_with_many_lights(oracle, monkeypatch):
             ref, _ = oracle.render(fs, Camera(), 640, 360, max_depth=4, row_step=24)
             rows = list(range(0, 360, 24))
             assert np.array_equal(gpu[rows], ref[rows]), f"9 lights, profiling {profiling}"
+
+
+def test_adversarial_scenes_with_the_grid(oracle):
+    """The scenes of test_gpu_adversarial.py (a few hundred spheres each: by itself the library would not
+    build a grid for them) with the grid forced: large offsets and scales, tangent pencils, a far camera,
+    degenerate spheres, lights and cameras, hit points far outside the served region."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("adversarial_scenes", os.path.join(os.path.dirname(__file__), "test_gpu_adversarial.py"))
+    adv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(adv)
+    with RenderContext() as c:
+        c.set_profiling(True)
+        for scale, offset in [(1.0, (1e3, -2e3, 5e2)), (1.0, (-1e5, 3e4, 1e5)), (100.0, (0.0, 0.0, 0.0)), (0.02, (1e3, 1e3, 1e3))]:
+            adv.test_scaled_and_translated_scenes(c, oracle, scale, offset)
+        adv.test_camera_far_from_the_cluster(c, oracle)
+        adv.test_degenerate_spheres_in_a_valid_scene(c, oracle)
+        adv.test_lights_in_awkward_places(c, oracle)
+        adv.test_open_scene_with_far_hits(c, oracle)
+        adv.test_enclosing_sphere_and_many_lights(c, oracle)
