@@ -16,11 +16,13 @@ Printed by rank 0: one JSON line with
                step ends with the frame in rank 0's DEVICE memory
   roofline     the levels stage, i.e. everything between the primary-ray kernel and the final
                shading passes: one k_reflect launch per level (the reflection rays' closest-hit
-               walks, on a second stream; k_reflect_chunks + k_reflect_finish for small levels of
-               many-chunk scenes) beside one k_plain launch per level (light rays and shading of the
+               walks over the LDS-staged scene; k_reflect_grid, one walk per lane through the spheres'
+               uniform grid, for scenes of more than 1024 spheres) beside one k_plain launch per level
+               on a second stream (light rays and shading of the
                records that reflect nothing; k_shade_lights for short queues of many-light scenes),
                or on small frames one k_trace_levels launch that does both.  The FLOP the stage EXECUTED per frame
-               (filter evaluations of rays against spheres and bounding balls, per-origin terms,
+               (filter evaluations of rays against spheres and bounding balls - a cell a grid walk
+               visits counts as one -, per-origin terms,
                exact Intersect of the candidates and of the spheres the lights' direction tables
                list, plane and triangle tests; from the library's work counters) / its HIP-event
                time, against the 157.3 TFLOP/s vector-FP32 peak.  `algorithmic_tflops` prices the same launch at
@@ -295,7 +297,7 @@ def main() -> None:
                 "timed_step_ends": "frame in device memory of rank 0 (see handoff for the host copy)",
             },
             "roofline": {
-                "bound": "valu-fp32", "kernel": "levels stage of a frame: k_reflect (or k_reflect_chunks + k_reflect_finish) per level (reflection "
+                "bound": "valu-fp32", "kernel": "levels stage of a frame: k_reflect (many-chunk scenes: k_reflect_grid) per level (reflection "
                                                  "rays) on a second stream beside k_plain (or k_shade_lights) per level (light rays + shading "
                                                  "of plain records); 'launch' = one frame's stage",
                 "achieved": round(executed, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
@@ -321,13 +323,17 @@ def main() -> None:
             # Render() ends with the pixels in host memory (MyApplication.cs:420): rt_render into a
             # pageable array, and into a page-locked one where the system allows registering it.
             out = np.empty((H, W), dtype=np.int32)
-            reps = 5 if args.config == "c3" else 2
+            reps = 5
 
             def host_ms() -> float:
-                ctx.render(cam, W, H, DEPTH, out=out)
+                for _ in range(2):   # (staging buffers, events and the library's own streams are set up by the first calls)
+                    ctx.render(cam, W, H, DEPTH, out=out)
                 t = time.perf_counter()
                 for _ in range(reps):
+                    tt = time.perf_counter()
                     ctx.render(cam, W, H, DEPTH, out=out)
+                    if os.environ.get("RT_BENCH_DEBUG"):
+                        print(f"[bench] rt_render {(time.perf_counter() - tt) * 1e3:.3f} ms", file=sys.stderr, flush=True)
                 return (time.perf_counter() - t) / reps * 1e3
 
             pageable = host_ms()
