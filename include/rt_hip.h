@@ -131,7 +131,10 @@ typedef struct rt_stats {
     uint64_t filter_ray_tests; /* (ray, sphere or bounding ball) pairs the filter evaluated:
                                   what the kernels executed in place of sphere_tests; groups
                                   of spheres whose bounding ball no ray of a wave can meet
-                                  are skipped                                               */
+                                  are skipped; for scenes of more than 1024 spheres the cells
+                                  the reflection rays' walks through the spheres' uniform grid
+                                  visit count here too, and the spheres those walks test as
+                                  exact_candidates                                          */
     uint64_t filter_origin_terms; /* (ray origin, sphere or ball) pairs for which the filter's
                                   per-origin term was formed (secondary and shadow rays)    */
     uint64_t primary_filter_ray_tests; /* the primary rays' share of filter_ray_tests ...   */
