@@ -738,8 +738,8 @@ void build_light_tables(PackedScene &out)
 
 // ---------------------------------------------------------------------------------------
 // Uniform grid over the spheres: what a reflection ray's closest-hit search walks instead of the
-// whole scene (rt_kernels.hip, "Grid walk").  A cell lists the spheres whose WIDENED box touches
-// it; the kernel runs the exact, literal Sphere.Intersect over the lists of the cells the ray
+// whole scene (rt_kernels.hip, "Grid walk").  A cell lists the spheres whose WIDENED ball comes
+// within the walk's slack of it; the kernel runs the exact, literal Sphere.Intersect over the lists of the cells the ray
 // passes, nearest first, and stops once its closest hit so far lies before the parameter at which
 // it leaves the cells visited.  What makes that lose nothing the reference accepts:
 //   * If the reference accepts the pair (ray, sphere i) with parameter t_ref, the point o + t_ref d
@@ -753,8 +753,10 @@ void build_light_tables(PackedScene &out)
 //   * The walk's cell sequence is that of a ray whose plane crossings are off by at most a few
 //     1e-4 cells (cell coordinates up to ~400 in magnitude, a handful of roundings): every point
 //     of the real ray up to the parameter at which the walk leaves a cell lies within GRID_EPS
-//     cells of a visited cell, and the boxes are widened by that much more.  So a sphere that is
-//     in none of the visited cells' lists is first met by the real ray beyond that parameter.
+//     cells (per axis) of a visited cell, and a sphere is listed in every cell whose distance from
+//     its centre is at most R_i plus that slack as a length.  So if the hit the reference accepts
+//     lies before the parameter at which the walk leaves its last cell, some visited cell lists the
+//     sphere; a sphere in none of the visited cells' lists is hit, if at all, beyond that parameter.
 // The grid is defined by the FP32 parameters the kernel uses (cell coordinate of x = (x - gr_lo) *
 // gr_ih in real arithmetic); the boxes are binned against those same numbers in double.
 // No grid (the kernels that walk the LDS-staged scene are used): fewer than RT_GRID_MIN_SPHERES usable

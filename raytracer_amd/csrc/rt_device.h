@@ -93,7 +93,7 @@ struct DevScene {
     float lt_near;
     // Uniform grid over the spheres (rt_api.cpp, build_sphere_grid; rt_kernels.hip, "Grid walk"): cell
     // (x, y, z) = gr_cells[(z * gr_n[1] + y) * gr_n[0] + x] = {first entry, entries} of the spheres whose
-    // widened box touches the cell: gr_sph {centre, r*r} and gr_orig (host primitive index) per entry.  The
+    // widened ball touches the cell: gr_sph {centre, r*r} and gr_orig (host primitive index) per entry.  The
     // lists hold every sphere the reference can accept for a ray whose ORIGIN lies in the box gr_reg_lo ..
     // gr_reg_hi; other origins evaluate every sphere.  gr_n[0] = 0: no grid.
     const uint2 *gr_cells;

@@ -140,3 +140,20 @@ def test_adversarial_scenes_with_the_grid(oracle):
         adv.test_lights_in_awkward_places(c, oracle)
         adv.test_open_scene_with_far_hits(c, oracle)
         adv.test_enclosing_sphere_and_many_lights(c, oracle)
+
+
+def test_grid_through_the_entry_point_that_allocates_nothing(oracle):
+    """The grid walk with the ray queues in the library's fixed scratch array (rt_render_rows_device_noalloc):
+    the same pixels as through the allocating entry point, on the 64k-sphere scene and a 1k-sphere one."""
+    import torch
+    stream = torch.cuda.Stream()
+    for fs, w, h, depth in ((scene_64k().flatten(), 128, 72, 4), (scene_1k().flatten(), 200, 120, 3)):
+        with RenderContext() as c:
+            c.set_scene(fs)
+            want = torch.full((h, w), -1, dtype=torch.int32, device="cuda")
+            got = torch.full((h, w), -2, dtype=torch.int32, device="cuda")
+            c.render_rows_device(Camera(), w, h, 0, h, depth, want.data_ptr(), stream.cuda_stream)
+            c.frame_status()
+            c.render_rows_device_noalloc(Camera(), w, h, 0, h, depth, got.data_ptr(), stream.cuda_stream)
+            c.frame_status()
+            assert torch.equal(got, want)
