@@ -343,6 +343,11 @@ def main() -> None:
                 ctx.unpin_pixels()
             except RtError as e:
                 pinned = f"refused ({e.message.split(';')[0]})"
+            # ... and into a page-locked framebuffer of the library's own (rt_alloc_pixels): the direct DMA,
+            # no staging and no move by the caller's thread.
+            out = ctx.alloc_pixels(H, W)
+            owned = round(host_ms(), 4)
+            ctx.unpin_pixels()
             # The same frames with two in flight, each in a render context of its own (a host that
             # presents from device memory can enqueue frame i + 1 before frame i is done): the idle
             # stretches of one frame's chain of levels are filled by the other's kernels.
@@ -370,6 +375,7 @@ def main() -> None:
                                  "note": "not `value`: two render contexts on the one GPU, frames enqueued back to back "
                                          "without waiting; `value` is one frame at a time, what a blocking Render() sees"}
             handoff = {"rt_render_pageable_ms": round(pageable, 4), "rt_render_pinned_ms": pinned,
+                       "rt_render_library_framebuffer_ms": owned,
                        "note": "whole rt_render calls (kernels + copy into the caller's int[w*h]); a frame this size is "
                                "rendered in row blocks whose copies overlap the next block's kernels"}
         line["handoff"] = handoff

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RT_API_VERSION 5
+#define RT_API_VERSION 6
 
 /* Primitive type codes — the reference's own flatten uses exactly these
  * (MyApplication.cs:161,166,173). */
@@ -240,6 +240,17 @@ int rt_render(rt_ctx *ctx, const rt_camera *camera, int width, int height,
  */
 int rt_pin_pixels(rt_ctx *ctx, int32_t *pixels, int64_t count);
 int rt_unpin_pixels(rt_ctx *ctx);
+
+/*
+ * The same hand-off for hosts that can present from a native pointer: a framebuffer of `count` pixels in
+ * page-locked memory the LIBRARY allocates (works where the system refuses to page-lock user memory).
+ * rt_render into *pixels_out (or any sub-range of it) writes it with the DMA itself, no staging, no move
+ * by the caller's thread.  The buffer replaces whatever range rt_pin_pixels registered, and lives until
+ * rt_unpin_pixels, the next rt_alloc_pixels / rt_pin_pixels, or rt_destroy.  In the reference the host
+ * would hand this pointer to GL.TexImage2D in place of screen.pixels (template.cs:199) and let Surface's
+ * drawing helpers write through it.  No counterpart in the reference.
+ */
+int rt_alloc_pixels(rt_ctx *ctx, int64_t count, int32_t **pixels_out);
 
 /*
  * Render rows [row_begin, row_end) of a width x height frame on the context's

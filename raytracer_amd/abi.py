@@ -138,6 +138,7 @@ EXPORTS = {
     "rt_fxaa_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rt_pin_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "rt_unpin_pixels": (C.c_int, [C.c_void_p]),
+    "rt_alloc_pixels": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(rt_stats)]),
     "rt_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
 }

@@ -157,6 +157,7 @@ struct rt_ctx {
     hipEvent_t part_ev[RT_MAX_FRAME_PARTS] = {};
     int32_t *pinned = nullptr;     // the host's own framebuffer, page-locked by rt_pin_pixels
     void *pinned_base = nullptr;   // start of the registered pages
+    bool pinned_owned = false;     // the range is page-locked memory of the library's own (rt_alloc_pixels)
     size_t pinned_count = 0;
     double copy_ms = 0.0, gather_ms = 0.0;
     std::vector<int> last_rows;    // row split of the last rt_render (n_dev + 1 entries)
@@ -1634,7 +1635,7 @@ void rt_destroy(rt_ctx *ctx)
     for (hipEvent_t e : ctx->part_ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
-    if (ctx->pinned) (void)hipHostUnregister(ctx->pinned_base);
+    if (ctx->pinned) (void)(ctx->pinned_owned ? hipHostFree(ctx->pinned_base) : hipHostUnregister(ctx->pinned_base));
     delete ctx;
 }
 
@@ -2069,10 +2070,12 @@ int rt_unpin_pixels(rt_ctx *ctx)
             HIP_TRY(ctx, hipStreamSynchronize(d.stream));
         }
         void *p = ctx->pinned_base;
+        const bool owned = ctx->pinned_owned;
         ctx->pinned = nullptr;
         ctx->pinned_base = nullptr;
         ctx->pinned_count = 0;
-        HIP_TRY(ctx, hipHostUnregister(p));
+        ctx->pinned_owned = false;
+        HIP_TRY(ctx, owned ? hipHostFree(p) : hipHostUnregister(p));
     }
     return RT_OK;
     });
@@ -2099,6 +2102,27 @@ int rt_pin_pixels(rt_ctx *ctx, int32_t *pixels, int64_t count)
     ctx->pinned_base = (void *)lo;
     ctx->pinned = pixels;
     ctx->pinned_count = (size_t)count;
+    return RT_OK;
+    });
+}
+
+int rt_alloc_pixels(rt_ctx *ctx, int64_t count, int32_t **pixels_out)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!pixels_out) return fail(ctx, RT_ERR_INVALID_ARG, "pixels_out is NULL");
+    *pixels_out = nullptr;
+    if (count <= 0 || count > INT32_MAX) return fail(ctx, RT_ERR_INVALID_ARG, "bad framebuffer size %lld", (long long)count);
+    int rc = rt_unpin_pixels(ctx);
+    if (rc != RT_OK) return rc;
+    return guarded(ctx, [&]() -> int {
+    HIP_TRY(ctx, hipSetDevice(ctx->dev[0].device));
+    void *p = nullptr;
+    HIP_TRY(ctx, hipHostMalloc(&p, (size_t)count * sizeof(int32_t), hipHostMallocDefault));
+    ctx->pinned_base = p;
+    ctx->pinned = static_cast<int32_t *>(p);
+    ctx->pinned_count = (size_t)count;
+    ctx->pinned_owned = true;
+    *pixels_out = ctx->pinned;
     return RT_OK;
     });
 }

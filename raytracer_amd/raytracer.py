@@ -86,6 +86,17 @@ class RenderContext:
         self._check(self._lib.rt_unpin_pixels(self._ctx))
         self._pinned_keepalive = None
 
+    def alloc_pixels(self, height: int, width: int) -> np.ndarray:
+        """rt_alloc_pixels: a height x width int32 framebuffer in page-locked memory of the library's own
+        (a view, valid until unpin_pixels(), the next alloc_pixels() / pin_pixels(), or close());
+        render(out=...) into it, or into a row range of it, is written by the DMA itself."""
+        import ctypes as C
+        p = C.c_void_p()
+        self._check(self._lib.rt_alloc_pixels(self._ctx, int(height) * int(width), C.byref(p)))
+        buf = (C.c_int32 * (int(height) * int(width))).from_address(p.value)
+        self._pinned_keepalive = None
+        return np.frombuffer(buf, dtype=np.int32).reshape(height, width)
+
     def set_profiling(self, enable) -> None:
         """rt_set_profiling: False / 0 off, True / 1 counters and kernel timing, 2 kernel timing only."""
         self._check(self._lib.rt_set_profiling(self._ctx, int(enable)))

@@ -179,6 +179,35 @@ def test_interleaved_bands_tile_the_frame(ctx):
         ctx.render_bands_device(cam, 8, 8, 16, 2, 2, depth, 0, 0)
 
 
+def test_library_owned_framebuffer_takes_the_direct_copy(oracle):
+    """rt_alloc_pixels: a page-locked framebuffer of the library's own (works where user memory cannot be
+    page-locked): frames rendered into it - whole, a sub-range, a large frame rendered in row blocks, a
+    frame from two device states - are the frames the staged path delivers; the buffer is replaced by the
+    next one and released by rt_unpin_pixels."""
+    fs, cam = default_scene().flatten(), Camera()
+    with RenderContext() as c:
+        c.set_scene(fs)
+        plain = c.render(cam, 320, 200, 5)
+        fb = c.alloc_pixels(2 * 200 + 1, 320)
+        fb[:] = -1
+        whole = c.render(cam, 320, 200, 5, out=fb[:200])
+        assert np.array_equal(whole.reshape(200, 320), plain)
+        part = c.render(cam, 320, 200, 5, out=fb[200:400])
+        assert np.array_equal(part.reshape(200, 320), plain) and (fb[400] == -1).all()
+        big = c.alloc_pixels(1600, 2048)           # replaces the first buffer; 3.3 M pixels: rendered in row blocks
+        staged = c.render(cam, 2048, 1600, 3)
+        direct = c.render(cam, 2048, 1600, 3, out=big)
+        assert np.array_equal(direct.reshape(1600, 2048), staged)
+        c.unpin_pixels()
+        assert np.array_equal(c.render(cam, 320, 200, 5), plain)
+        ref, _ = oracle.render(fs, cam, 320, 200, max_depth=5)
+        assert np.array_equal(plain, ref)
+    with RenderContext([0, 0]) as c2:               # two device states on the one device: the gather path
+        c2.set_scene(fs)
+        fb = c2.alloc_pixels(200, 320)
+        assert np.array_equal(c2.render(cam, 320, 200, 5, out=fb).reshape(200, 320), plain)
+
+
 def test_pinned_framebuffer_takes_the_direct_copy(oracle):
     """rt_pin_pixels: frames rendered into the registered array (whole or a sub-range) and into
     an unregistered one are the same frames."""
