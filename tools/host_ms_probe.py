@@ -1,6 +1,14 @@
-import sys, time, os
-import numpy as np, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+#!/usr/bin/env python3
+"""Per-call times of rt_render (frame into host memory) and rt_render_rows_device on the 64k-sphere scene,
+call by call: what the first calls after a change of entry point or stream cost."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_amd import Camera, RenderContext, scene_64k
 ctx = RenderContext([0]); ctx.set_scene(scene_64k().flatten())
 W,H,D = 1920,1080,8
