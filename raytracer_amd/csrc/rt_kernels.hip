@@ -231,7 +231,7 @@ __device__ __forceinline__ void load_record(const float4 *a, const float4 *b, fl
 // Append up to N new hit records per thread to level `level`, with ONE atomic per queue per
 // WORKGROUP: a single counter word takes only ~90 returning atomics per microsecond, and a
 // frame appends hundreds of thousands of waves' worth of records.  Every thread of the
-// workgroup must call it (two barriers inside); blk is a __shared__ int[12].
+// workgroup must call it (two barriers inside); blk is a __shared__ int[2 * waves + 2] or larger.
 //   A records (need a reflection trace) fill the level from the front, B records from the back.
 template <int N, bool THROUGH = true>
 __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &s, int level, int *blk,
@@ -273,11 +273,11 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
         if (ta | tb)
             before = atomicAdd(reinterpret_cast<unsigned long long *>(&f.cnt[2 * level]),
                                ((unsigned long long)(unsigned)tb << 32) | (unsigned long long)(unsigned)ta);
-        blk[8] = (int)(unsigned)before;
-        blk[9] = (int)(unsigned)(before >> 32);
+        blk[2 * nwaves] = (int)(unsigned)before;
+        blk[2 * nwaves + 1] = (int)(unsigned)(before >> 32);
     }
     __syncthreads();
-    const int base_a = blk[8] + blk[2 * wave], base_b = blk[9] + blk[2 * wave + 1];
+    const int base_a = blk[2 * nwaves] + blk[2 * wave], base_b = blk[2 * nwaves + 1] + blk[2 * wave + 1];
 #pragma unroll
     for (int k = 0; k < N; k++) {
         if (valid[k]) {
@@ -1010,14 +1010,24 @@ __device__ __forceinline__ bool ball_in_cone(const TileCone &tc, const float4 b,
 #ifndef RT_PRIMARY_WAVES
 #define RT_PRIMARY_WAVES 5
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_PRIMARY_WAVES)))
+// A workgroup of RT_PRIMARY_THREADS / 64 waves takes a tile of PRIM_TILE_W x 32 pixels per trip (a wave: 16 x 16).
+// Eight waves: a trip costs two contended returning atomics (the tile claim, the records' slots), and at 3840x2160
+// their rate on one address bounds the kernel: 0.123 ms with four waves per workgroup (8100 trips), 0.095 with
+// eight, 0.103 with sixteen (the barrier then waits for the slowest of sixteen tiles).
+#ifndef RT_PRIMARY_THREADS
+#define RT_PRIMARY_THREADS 512
+#endif
+#define PRIM_WAVES_X (RT_PRIMARY_THREADS / 128)
+#define PRIM_TILE_W (16 * PRIM_WAVES_X)
+#define PRIM_CLAIM (RT_PRIMARY_THREADS / 32 + 2)   // blk words of the tile claims, behind push_records' own
+__global__ void __launch_bounds__(RT_PRIMARY_THREADS) __attribute__((amdgpu_waves_per_eu(RT_PRIMARY_WAVES)))
 k_primary(DevScene s, DevCamera cam, DevFrame f, int32_t *pixels)
 {
-    __shared__ int blk[12];
+    __shared__ int blk[PRIM_CLAIM + 2];
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rows = cam.rows;
-    const int tiles_x = (cam.width + 31) >> 5, tiles_y = (rows + 31) >> 5;
+    const int tiles_x = (cam.width + PRIM_TILE_W - 1) / PRIM_TILE_W, tiles_y = (rows + 31) >> 5;
     const int ntiles = tiles_x * tiles_y;
     const int nsp = s.ns_padded;
     const int nchk = (nsp + RT_CHUNK - 1) / RT_CHUNK, nsup = nsp / RT_SUPER;
@@ -1028,7 +1038,7 @@ k_primary(DevScene s, DevCamera cam, DevFrame f, int32_t *pixels)
     const float4 only_chunk = nchk == 1 && lane < RT_CHUNK / RT_SUPER && lane < nsup ? s.sup_b[lane] : no_ball;
     // A workgroup's first tile is its index; the others are claimed from a counter (tiles cost
     // very different amounts), each claim sent before the tile it follows so that its answer
-    // travels while that tile is traced.  blk[10], blk[11]: the answer, alternating per trip.
+    // travels while that tile is traced.  blk[PRIM_CLAIM], blk[PRIM_CLAIM + 1]: the answer, alternating per trip.
     int trip = 0;
 #ifdef RT_PRIMARY_CLOCKS
     unsigned long long pclk[8] = {}, ptl = __builtin_readcyclecounter();
@@ -1040,8 +1050,8 @@ k_primary(DevScene s, DevCamera cam, DevFrame f, int32_t *pixels)
         int claimed = 0;
         if (threadIdx.x == 0) claimed = (int)gridDim.x + atomicAdd(&f.sched->next_primary, 1);
         const int tx = tile % tiles_x, ty = tile / tiles_x;
-        const int x0 = tx * 32 + (wave & 1) * 16 + (lane & 7) * 2;
-        const int y0 = ty * 32 + (wave >> 1) * 16 + (lane >> 3) * 2;   // row of the output block
+        const int x0 = tx * PRIM_TILE_W + (wave % PRIM_WAVES_X) * 16 + (lane & 7) * 2;
+        const int y0 = ty * 32 + (wave / PRIM_WAVES_X) * 16 + (lane >> 3) * 2;   // row of the output block
         bool inside[PRIM_PX];
         int px[PRIM_PX], py[PRIM_PX], ly[PRIM_PX];
         f3 d[PRIM_PX];
@@ -1211,9 +1221,9 @@ k_primary(DevScene s, DevCamera cam, DevFrame f, int32_t *pixels)
             rec_hit[k] = add3(o, scale3(d[k], best_t[k]));
             if (inside[k] && !hit) pixels[pix] = 0;  // MyApplication.cs:423
         }
-        if (threadIdx.x == 0) blk[10 + (trip & 1)] = claimed;
+        if (threadIdx.x == 0) blk[PRIM_CLAIM + (trip & 1)] = claimed;
         push_records<PRIM_PX, false>(f, s, 0, blk, rec_valid, rec_prim, rec_hit, d, rec_parent);   // (barriers)
-        tile = blk[10 + (trip & 1)];
+        tile = blk[PRIM_CLAIM + (trip & 1)];
         PMARK(6)
     }
     // Counter words in the order of DevCounters: cone tests count as filter evaluations.
@@ -3174,8 +3184,10 @@ static bool multi_chunk(const DevScene &s) { return s.ns_padded > SPH_CHUNK; }
 void rtk_primary(const DevScene &s, const DevCamera &cam, const DevFrame &f, int32_t *pixels, int grid_blocks,
                  hipStream_t stream)
 {
-    const int ntiles = ((cam.width + 31) / 32) * ((cam.rows + 31) / 32);  // 32x32 pixels per workgroup trip
-    const dim3 g(ntiles < grid_blocks ? ntiles : grid_blocks), b(256);
+    const int ntiles = ((cam.width + PRIM_TILE_W - 1) / PRIM_TILE_W) * ((cam.rows + 31) / 32);  // pixels per workgroup trip
+    grid_blocks = grid_blocks * 256 / RT_PRIMARY_THREADS;   // (the caller counts workgroups of four waves)
+    if (grid_blocks < 1) grid_blocks = 1;
+    const dim3 g(ntiles < grid_blocks ? ntiles : grid_blocks), b(RT_PRIMARY_THREADS);
     hipLaunchKernelGGL(k_primary, g, b, 0, stream, s, cam, f, pixels);
 }
 
