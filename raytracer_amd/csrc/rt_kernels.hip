@@ -1008,7 +1008,7 @@ __device__ __forceinline__ bool ball_in_cone(const TileCone &tc, const float4 b,
 #define PRIM_PX 4   // pixels per lane (2x2)
 
 #ifndef RT_PRIMARY_WAVES
-#define RT_PRIMARY_WAVES 5
+#define RT_PRIMARY_WAVES 4   // (with workgroups of eight waves: 5 spills, 6 is slower)
 #endif
 // A workgroup of RT_PRIMARY_THREADS / 64 waves takes a tile of PRIM_TILE_W x 32 pixels per trip (a wave: 16 x 16).
 // Eight waves: a trip costs two contended returning atomics (the tile claim, the records' slots), and at 3840x2160
