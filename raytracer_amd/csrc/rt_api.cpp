@@ -582,7 +582,8 @@ int light_table_bins(size_t spheres)
         while (n < atoi(env) && n < 1024) n *= 2;
         return n;
     }
-    return spheres <= 256 ? 32 : spheres <= 4096 ? 64 : spheres <= 16384 ? 128 : 256;
+    // (65536 spheres, 16 lights: 128 bins 4.04 ms per frame, 256 bins 4.20, 64 bins 4.65, 512 bins 4.74)
+    return spheres <= 256 ? 32 : spheres <= 4096 ? 64 : spheres <= 262144 ? 128 : 256;
 }
 
 void build_light_tables(PackedScene &out)
@@ -764,7 +765,7 @@ void build_light_tables(PackedScene &out)
 // spheres, extents that are not finite, or lists that would grow out of proportion (a sphere that
 // covers thousands of cells), or a scene of one chunk (below).  RT_HIP_GRID_DENSITY = cells
 // per sphere (default 2); RT_HIP_GRID_REGION = how far the served region reaches beyond the spheres'
-// extent, in units of its largest side (default 0.5).
+// extent, in units of its largest side (default 1).
 // ---------------------------------------------------------------------------------------
 constexpr size_t RT_GRID_MIN_SPHERES = 64;
 constexpr int RT_GRID_MAX_AXIS = 256;
@@ -786,7 +787,10 @@ void build_sphere_grid(PackedScene &out)
     if (mode == 0 || (mode != 2 && out.sph.size() <= (size_t)RT_CHUNK)) return;
     const char *dens_env = getenv("RT_HIP_GRID_DENSITY"), *reg_env = getenv("RT_HIP_GRID_REGION");
     const double density = dens_env && atof(dens_env) > 0.0 ? atof(dens_env) : 2.0;
-    const double reach = reg_env && atof(reg_env) >= 0.0 ? atof(reg_env) : 0.5;
+    // (an origin outside the region evaluates every sphere: with the 64k-sphere scene's room wall 0.37 sides
+    // away from the spheres, a region of 0.25 sides costs 84 ms per frame against 3.6; the wider region's wider
+    // lists cost 1 %)
+    const double reach = reg_env && atof(reg_env) >= 0.0 ? atof(reg_env) : 1.0;
     const double u24 = 1.0 / 16777216.0;
     std::vector<uint32_t> use;
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -1348,7 +1352,10 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     const int light_below_env = light_below_str ? atoi(light_below_str) : -1;
     const int nl = d.scene.nl;
     fr.light_waves = fused || nl < 3 || light_below_env == 0 ? 0 : nl >= 12 ? 16 : nl >= 6 ? 8 : 4;
-    fr.light_split_below = light_below_env > 0 ? light_below_env : 64 * 1024 / share;
+    // (The more lights, the longer the queues it pays for: a wave of k_shade_lights looks one light up for 64
+    // neighbouring records - one table, nearby cells - where a lane of k_plain goes through all the tables.
+    // 16 lights: 4.04 ms per frame with queues below 64 K records, 3.88 below 256 K, 3.64 below 512 K or 1 M, 4.3 for all.)
+    fr.light_split_below = light_below_env > 0 ? light_below_env : std::max(64, 32 * nl) * 1024 / share;
     // Scenes of several chunks or many lights, one launch per level: the records of a level >= 1 are put
     // into the order of their hit points' position bins before the level is used (k_bin_*).
     // RT_HIP_BIN_MIN=n (tuning aid): for levels of at least n records; 0 = never.
