@@ -1345,7 +1345,11 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // records per workgroup, the scene spread over the workgroup's waves.  RT_HIP_SPREAD_BELOW=n (tuning
     // aid; 0 = never).
     const char *spread_below_str = getenv("RT_HIP_SPREAD_BELOW");
-    fr.spread_below = fused || grid ? 0 : spread_below_str ? atoi(spread_below_str) : std::max(1, d.num_cus * 2 / share);
+    // (on a large frame the plain records' launches keep the device busy beside the chain, and the four times as
+    // many workgroups of the spread form only take from them: 3840x2160 0.552 ms with a bound of 128 tiles
+    // against 0.562 with 512, 1920x1080 0.259 against 0.250)
+    fr.spread_below = fused || grid ? 0 : spread_below_str ? atoi(spread_below_str)
+                                          : std::max(1, (tiles0 >= 16384 ? d.num_cus / 2 : d.num_cus * 2) / share);
     // Scenes with several lights, one launch per level: short queues are shaded with the lights spread
     // over the waves of a workgroup (k_shade_lights).  RT_HIP_LIGHT_SPLIT_BELOW=n (tuning aid; 0 = never).
     const char *light_below_str = getenv("RT_HIP_LIGHT_SPLIT_BELOW");   // (these knobs are read at every call)
