@@ -1447,7 +1447,14 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     else HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, FRAME_CONTROL_BYTES, stream));
     d.timed = ctx->profiling != 0;
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
-    const int blocks = std::max(1, std::min({(P + 255) / 256, d.num_cus * 8 / std::max(1, ctx->share), RT_COUNTER_SLOTS}));
+    // Workgroups per compute unit of the per-level launches (RT_HIP_REFLECT_BLOCKS / RT_HIP_PLAIN_BLOCKS /
+    // RT_HIP_LIGHT_BLOCKS, tuning aids, override the defaults).
+    auto per_cu = [](const char *name, int dflt) {
+        const char *v = getenv(name);
+        return v && atoi(v) > 0 ? atoi(v) : dflt;
+    };
+    const int blocks = std::max(1, std::min({(P + 255) / 256, d.num_cus * per_cu("RT_HIP_REFLECT_BLOCKS", 8) / std::max(1, ctx->share),
+                                             RT_COUNTER_SLOTS}));
     // k_primary's workgroups claim their 32x32-pixel tiles dynamically: as many workgroups as are
     // resident at once (4 per compute unit) when each gets several tiles, twice that on small frames
     // (measured: 3840x2160 0.161 against 0.170 ms, 1920x1080 0.050 against 0.048 ms).
@@ -1467,8 +1474,8 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     if (!fused) {
         // (counting kernels add to per-workgroup counter slots without atomics: one stream then)
         const bool two_streams = !level_kernels && !counting && max_depth > 0;
-        const int plain_blocks = std::max(1, std::min({tiles0, d.num_cus * 16 / share, RT_COUNTER_SLOTS}));
-        const int light_blocks = std::max(1, std::min(d.num_cus * 8 / share, RT_COUNTER_SLOTS));
+        const int plain_blocks = std::max(1, std::min({tiles0, d.num_cus * per_cu("RT_HIP_PLAIN_BLOCKS", 16) / share, RT_COUNTER_SLOTS}));
+        const int light_blocks = std::max(1, std::min(d.num_cus * per_cu("RT_HIP_LIGHT_BLOCKS", 8) / share, RT_COUNTER_SLOTS));
         // The chain stays on the caller's stream (a dependency between two launches of one stream costs
         // ~6 us, across streams ~12, and the chain is the frame's critical path); the plain records'
         // launches go to the second stream, except the deepest level's, which the chain ends with.
