@@ -1418,11 +1418,14 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
         const size_t want = (size_t)fr.P * (size_t)max_depth * (size_t)std::max(nl, 1);
         // (not for a context that shares its device with others rendering at the same time: there the
         // tail of one frame is filled by the other frames' kernels anyway, and the extra traffic costs 5 %)
-        // (RT_HIP_EARLY_LIGHTS_MAX, tuning aid: the most lights it is used for.  With the 16 lights of the
-        // 64k-sphere scene the frame's tail shrinks by 1.2 ms and the stage grows by as much: 4.28 against
-        // 4.17 ms per frame, the device is busy either way.)
-        const char *lit_lights_env = getenv("RT_HIP_EARLY_LIGHTS_MAX");   // (read at every call)
-        const int lit_lights = lit_lights_env ? atoi(lit_lights_env) : 4;
+        // With more than four lights only for the levels of few reflecting records: their passes at the end of
+        // the frame are pure latency (16 lights: ~75 us per level however few its records), while a long queue
+        // costs its work wherever it runs (the 16 lights of the 64k-sphere scene with every level ahead: the
+        // frame's tail shrinks by 1.2 ms and the stage grows by as much).  RT_HIP_EARLY_LIGHTS_MAX: the most
+        // lights it is used for; RT_HIP_EARLY_LIGHTS_BELOW: the bound in records (0: every level); tuning aids.
+        const char *lit_lights_env = getenv("RT_HIP_EARLY_LIGHTS_MAX"), *lit_below_env = getenv("RT_HIP_EARLY_LIGHTS_BELOW");
+        const int lit_lights = lit_lights_env ? atoi(lit_lights_env) : 16;
+        fr.lit_below = nl <= 4 ? 0 : lit_below_env ? atoi(lit_below_env) : 65536;
         if (!fused && !fixed_scratch && share == 1 && max_depth > 0 && nl >= 1 && nl <= lit_lights &&
             (!early_env || atoi(early_env) != 0) &&
             want * sizeof(float4) <= RT_LIT_MAX_BYTES) {
@@ -1501,21 +1504,14 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
             if (tail_pair && k == max_depth - 1) {
                 rtk_plain_levels(d.scene, f, k - 1, k, dev_pixels, plain_blocks, where);
                 if (f.light_waves) {
-                    rtk_shade_lights(d.scene, f, k - 1, 0, dev_pixels, light_blocks, where);
-                    rtk_shade_lights(d.scene, f, k, 0, dev_pixels, light_blocks, where);
-                    if (f.lit) {
-                        rtk_shade_lights(d.scene, f, k - 1, 2, dev_pixels, light_blocks, where);
-                        rtk_shade_lights(d.scene, f, k, 2, dev_pixels, light_blocks, where);
-                    }
+                    rtk_shade_lights(d.scene, f, k - 1, f.lit ? 3 : 0, dev_pixels, light_blocks, where);
+                    rtk_shade_lights(d.scene, f, k, f.lit ? 3 : 0, dev_pixels, light_blocks, where);
                 }
                 continue;
             }
             rtk_trace(d.scene, f, k, false, dev_pixels, plain_blocks, where);
-            if (f.light_waves) rtk_shade_lights(d.scene, f, k, 0, dev_pixels, light_blocks, where);
-            if (f.lit && k < max_depth) {
-                rtk_lit_level(d.scene, f, k, plain_blocks, where);
-                if (f.light_waves) rtk_shade_lights(d.scene, f, k, 2, dev_pixels, light_blocks, where);
-            }
+            if (f.light_waves) rtk_shade_lights(d.scene, f, k, f.lit && k < max_depth ? 3 : 0, dev_pixels, light_blocks, where);
+            if (f.lit && k < max_depth) rtk_lit_level(d.scene, f, k, plain_blocks, where);
         }
         if (two_streams) {   // the reflecting records' shading below needs every plain level (and the light terms)
             HIP_TRY(ctx, hipEventRecord(d.ev_fork, d.aux));
@@ -1532,7 +1528,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // (the reflecting records; the deepest level has none)
     for (int k = max_depth - 1; k >= 0; k--) {
         rtk_shade_level(d.scene, f, k, dev_pixels, std::min(shade_blocks, RT_COUNTER_SLOTS), stream);
-        if (f.light_waves && !f.lit)
+        if (f.light_waves && (!f.lit || f.lit_below > 0))
             rtk_shade_lights(d.scene, f, k, 1, dev_pixels, std::max(1, std::min(d.num_cus * 8 / share, RT_COUNTER_SLOTS)), stream);
     }
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[3], stream));

@@ -218,6 +218,8 @@ struct DevFrame {
     // levels below max_depth and per light {what the light adds directly (rgb), distance * distance}.
     // Null: k_shade runs the whole light loop itself.
     float4 *lit;
+    int lit_below;         // > 0: only for levels of fewer than that many reflecting records (the others run their
+                           // whole light loop once their children are shaded)
     int light_waves;       // > 0: queues of fewer than light_split_below records are shaded with the lights spread
     int light_split_below; // over that many waves per 64 records (k_shade_lights)
     int spread_below;      // one-chunk scenes: levels with fewer reflecting tiles than this take 64 records per workgroup
@@ -253,7 +255,7 @@ void rtk_plain_levels(const DevScene &s, const DevFrame &f, int level_lo, int le
 void rtk_lit_level(const DevScene &s, const DevFrame &f, int level, int grid_blocks, hipStream_t stream);
 // A queue of a level with the lights spread over DevFrame::light_waves waves per 64 records; does nothing unless
 // the queue is shorter than DevFrame::light_split_below.  queue 0: the plain records, shaded; 1: the reflecting
-// records, shaded (their children are); 2: the reflecting records' light terms into DevFrame::lit.
+// records, shaded (their children are); 2: the reflecting records' light terms into DevFrame::lit; 3: 0 and 2.
 void rtk_shade_lights(const DevScene &s, const DevFrame &f, int level, int queue, int32_t *pixels, int grid_blocks,
                       hipStream_t stream);
 // Raytracer.Debug's rays: 16 floats per ray (rt_debug_ray's 14 words, then two of padding).

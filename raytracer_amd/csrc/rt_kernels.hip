@@ -1856,6 +1856,12 @@ __device__ __forceinline__ void combine_record(const DevScene &s, const DevFrame
     shade_store(f, level, parent, final, false, pixels);
 }
 
+// Are the light terms of a level of `na` reflecting records computed ahead of their children (DevFrame::lit)?
+__device__ __forceinline__ bool lit_ahead(const DevFrame &f, const int na)
+{
+    return f.lit != nullptr && (f.lit_below <= 0 || na < f.lit_below);
+}
+
 // One tile = 256 consecutive records of one queue of one level, one record per lane.
 // reflection_tile: records that need a reflection trace (queue "A") walk the scene with their
 // reflection ray and push the records of the next level; they are shaded later, when their
@@ -2708,7 +2714,7 @@ k_plain_tail(DevScene s, DevFrame f, int level, int level_hi, int32_t *pixels)
             const int ntiles = (n + 255) >> 8;
             for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) plain_tile<COUNT>(s, f, lv, tile, n, pixels, tc, pc);
         }
-        if (f.lit && lv < f.max_depth && !(f.light_waves > 0 && f.cnt[2 * lv] < f.light_split_below)) {
+        if (lv < f.max_depth && lit_ahead(f, f.cnt[2 * lv]) && !(f.light_waves > 0 && f.cnt[2 * lv] < f.light_split_below)) {
             const int na = f.cnt[2 * lv];
             const int ntiles = (na + 255) >> 8;
             for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -2727,6 +2733,7 @@ k_lit(DevScene s, DevFrame f, int level)
 {
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int n = f.cnt[2 * level];
+    if (!lit_ahead(f, n)) return;
     if (f.light_waves > 0 && n < f.light_split_below) return;   // k_shade_lights (reflecting = 2) takes this queue
     const int ntiles = (n + 255) >> 8;
     TestCount tc = {0, 0, 0, 0, 0, 0, 0};
@@ -2950,7 +2957,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
 {
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int na = f.cnt[2 * level];
-    if (f.lit) {   // the light terms are there (k_lit): only the sums are left
+    if (lit_ahead(f, na)) {   // the light terms are there (k_lit): only the sums are left
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na; i += gridDim.x * blockDim.x)
             combine_record(s, f, level, level * f.P + i, pixels);
         return;
@@ -2985,22 +2992,30 @@ __global__ void __launch_bounds__(64 * LIGHT_WAVES_MAX) k_shade_lights(DevScene 
 {
     __shared__ float terms[LIGHT_WAVES_MAX][6][64];
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
-    // reflecting = 2: the light terms of the reflecting records into DevFrame::lit, ahead of their children
-    // (what k_lit does for long queues); nothing is summed or stored elsewhere.
-    const bool ahead = reflecting == 2;
-    const int n = f.cnt[2 * level + (reflecting ? 0 : 1)];
-    if (!(n < f.light_split_below)) return;
+    // reflecting = 0: the plain records, shaded; 1: the reflecting records, shaded (their children are);
+    // 2: the light terms of the reflecting records into DevFrame::lit, ahead of their children (what k_lit does for
+    // long queues; nothing is summed or stored elsewhere); 3: 0 and 2 in one launch (both are chains of dependent
+    // reads that a short queue cannot hide: side by side they cost the time of one).
+    // Whichever queue is too long for this form, or has its light terms computed the other way, is left out.
+    const int nb = f.cnt[2 * level + 1], na = f.cnt[2 * level];
+    const bool want_plain = reflecting == 0 || reflecting == 3, want_ahead = reflecting == 2 || reflecting == 3;
+    const int tiles_b = want_plain && nb < f.light_split_below ? (nb + 63) >> 6 : 0;
+    const int tiles_a = (reflecting == 1 && na < f.light_split_below && !lit_ahead(f, na)) ||
+                                (want_ahead && level < f.max_depth && na < f.light_split_below && lit_ahead(f, na))
+                            ? (na + 63) >> 6 : 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
-    const int ntiles = (n + 63) >> 6;
     const int nl = s.nl;
     TestCount tc = {0, 0, 0, 0, 0, 0, 0};
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int job = blockIdx.x; job < tiles_b + tiles_a; job += gridDim.x) {
+        const bool queue_a = job >= tiles_b;              // (uniform over the workgroup)
+        const bool ahead = queue_a && want_ahead;
+        const int tile = queue_a ? job - tiles_b : job, n = queue_a ? na : nb;
         const int i = tile * 64 + lane;
         const bool active = i < n;
         const int ii = active ? i : n - 1;
-        const int slot = reflecting ? level * f.P + ii : (level + 1) * f.P - 1 - ii;
-        const bool through = !reflecting;   // as k_plain and k_shade read and write their records
-        const ShadeRecord r = shade_setup(s, f, slot, active, reflecting == 1, through);
+        const int slot = queue_a ? level * f.P + ii : (level + 1) * f.P - 1 - ii;
+        const bool through = !queue_a;   // as k_plain and k_shade read and write their records
+        const ShadeRecord r = shade_setup(s, f, slot, active, queue_a && !ahead, through);
         f3 final = mk3(0.0f, 0.0f, 0.0f);
         for (int l0 = 0; l0 < nl; l0 += W) {
             const int l = l0 + wave;

@@ -96,20 +96,22 @@ def test_clustered_spheres_and_an_outlier(oracle):
     frames_equal_oracle(oracle, s.flatten(), Camera(), 192, 108, 5, "clusters and an outlier")
 
 
-def test_light_terms_ahead_with_many_lights(oracle, monkeypatch):
-    """The reflecting records' light terms computed ahead of their children for up to 16 lights (the default
-    stops at four): long queues one record per lane, short ones with the lights spread over waves."""
-    monkeypatch.setenv("RT_HIP_EARLY_LIGHTS_MAX", "16")
+@pytest.mark.parametrize("below", ["0", "3000", "200000"])
+def test_light_terms_ahead_with_many_lights(oracle, monkeypatch, below):
+    """The reflecting records' light terms computed ahead of their children on scenes of more than four lights:
+    for every level, for the levels of fewer than 3000 reflecting records, of fewer than 200000 (by itself the
+    library takes 65536); long queues one record per lane, short ones with the lights spread over waves."""
+    monkeypatch.setenv("RT_HIP_EARLY_LIGHTS_BELOW", below)
     monkeypatch.setenv("RT_HIP_PIPELINE", "levels")
     for profiling in (1, 0):
         with RenderContext() as c:
             c.set_profiling(profiling)
-            for fs, cam, w, h, depth, key in ((scene_64k().flatten(), Camera(), 96, 54, 8, "64k"),):
-                c.set_scene(fs)
-                gpu = c.render(cam, w, h, depth)
-                if key not in _oracle_frames:
-                    _oracle_frames[key] = oracle.render(fs, cam, w, h, max_depth=depth)
-                assert np.array_equal(gpu, _oracle_frames[key][0]), f"64k spheres, profiling {profiling}"
+            fs, cam, w, h, depth, key = scene_64k().flatten(), Camera(), 96, 54, 8, "64k"
+            c.set_scene(fs)
+            gpu = c.render(cam, w, h, depth)
+            if key not in _oracle_frames:
+                _oracle_frames[key] = oracle.render(fs, cam, w, h, max_depth=depth)
+            assert np.array_equal(gpu, _oracle_frames[key][0]), f"64k spheres, profiling {profiling}"
             s = synthetic_scene(300, radius=(0.05, 0.3), seed=5)
             s.lights.clear()
             for i in range(9):
@@ -117,9 +119,10 @@ def test_light_terms_ahead_with_many_lights(oracle, monkeypatch):
             fs = s.flatten()
             c.set_scene(fs)
             gpu = c.render(Camera(), 640, 360, 4)     # level 0 is a long queue, the deep levels short ones
-            ref, _ = oracle.render(fs, Camera(), 640, 360, max_depth=4, row_step=24)
+            if "9 lights" not in _oracle_frames:
+                _oracle_frames["9 lights"] = oracle.render(fs, Camera(), 640, 360, max_depth=4, row_step=24)
             rows = list(range(0, 360, 24))
-            assert np.array_equal(gpu[rows], ref[rows]), f"9 lights, profiling {profiling}"
+            assert np.array_equal(gpu[rows], _oracle_frames["9 lights"][0][rows]), f"9 lights, profiling {profiling}"
 
 
 def test_adversarial_scenes_with_the_grid(oracle):
