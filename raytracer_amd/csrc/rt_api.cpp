@@ -296,6 +296,8 @@ struct PackedScene {
     std::vector<float> lt_reach;
     int lt_n = 0;
     float lt_near = 0.f;
+    int lt_tiers = 0;
+    float lt_tier_q[RT_LT_TIERS - 1] = {};
     // Uniform grid over the spheres (build_sphere_grid).
     std::vector<uint2> gr_cells;
     std::vector<float4> gr_sph;
@@ -539,6 +541,20 @@ void build_plain_balls(const PackedScene &out, size_t run, size_t pad, std::vect
 // max |p'|_1, Dmax = near + |L - centre|_1, m = 4e-3 * Dmax, and every cap is widened by 2e-4
 // rad, which covers the 1e-4 above, the rounding of (u, v) on the device (< 1e-6) and the
 // double arithmetic here.
+//
+// Tiers.  28.6u * B^2 is what the reference's cancellation in |o - p|^2 - r^2 can add to r^2, and for
+// small spheres and a B that covers the whole served region it exceeds r^2 itself (r = 0.0175, B = 20:
+// R_i = 1.84 r).  A SHORT ray cannot start far from a sphere it meets: if the reference accepts the
+// pair at t (0 < t < distance), then with B* = |o - p_i| itself in the bounds above
+//   B* <= t |d| + R_i(B*) + zeta(B*) <= distance (1 + 1e-6) + r_i + (sqrt(28.6u) + 8u) B*,
+// so B* <= (distance (1 + 1e-6) + r_i) (1 + 2e-3).  The tables are therefore built several times
+// over: tier k serves the rays (of served origins) whose length is at most d_k, with B the smaller
+// of the bound above at distance = d_k and the region's, with Dmax = min(d_k (1 + 1e-6), the
+// region's), and without the spheres that stay farther than d_k from the light (lt_reach); the last
+// tier has no d_k and is the table described above.  The kernel picks the first tier whose d_k^2
+// (1 - 1e-5) its own |o - L|^2 does not exceed (light_table_cell: that product differs from the
+// square of the reference's `distance` by a few ulp).  d_1 = 240 times the median radius (R_i = 1.05
+// r_i there), each further tier 2.5 times longer.
 // ---------------------------------------------------------------------------------------
 struct ConeNode {
     double cx, cy, cz, cosb, sinb;   // centre direction (face-local: u, v, axis) and angular radius of a uv square
@@ -595,6 +611,7 @@ void build_light_tables(PackedScene &out)
     out.lt_reach.clear();
     out.lt_n = 0;
     out.lt_near = 0.f;
+    out.lt_tiers = 0;
     if (ns == 0 || nl == 0) return;
     const int n = light_table_bins(ns);
     const double u24 = 1.0 / 16777216.0;
@@ -608,28 +625,54 @@ void build_light_tables(PackedScene &out)
     // far out as the lights.
     static const char *near_env = getenv("RT_HIP_LIGHT_NEAR");   // tuning aid: the factor below
     const double near = (near_env && atof(near_env) > 0.0 ? atof(near_env) : 2.0) * std::max((double)out.sph_l1max, light_l1);
-    // (B >= |o - p_i| per sphere: the origin's bound plus the sphere's own distance from the centre)
-    auto widened = [&](const float4 &sp) {
-        const double B = near + std::fabs(sp.x - cen[0]) + std::fabs(sp.y - cen[1]) + std::fabs(sp.z - cen[2]);
+    // The tiers' ray lengths d_k (the last tier: none).  RT_HIP_LIGHT_TIERS=1 (tuning aid): the last tier only.
+    std::vector<double> tier_d;
+    {
+        std::vector<float> radii;
+        for (const float4 &sp : out.sph)
+            if (usable_sphere(sp)) radii.push_back(std::sqrt(sp.w));
+        static const char *tiers_env = getenv("RT_HIP_LIGHT_TIERS");
+        const int most = tiers_env && atoi(tiers_env) >= 1 ? std::min(atoi(tiers_env), RT_LT_TIERS) : RT_LT_TIERS;
+        if (!radii.empty()) {
+            std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+            static const char *d1_env = getenv("RT_HIP_LIGHT_TIER_D1");   // tuning aid: the first tier's ray length
+            double dk = d1_env && atof(d1_env) > 0.0 ? atof(d1_env) : 240.0 * (double)radii[radii.size() / 2];
+            // (a tier that reaches most of the way to the region's bound gains nothing over the last one)
+            while ((int)tier_d.size() + 1 < most && dk > 0.0 && dk < 0.5 * (near + light_l1)) {
+                tier_d.push_back(dk);
+                dk *= 2.5;
+            }
+        }
+        tier_d.push_back(INFINITY);
+    }
+    const size_t tiers = tier_d.size();
+    // (B >= |o - p_i| per sphere: the origin's bound plus the sphere's own distance from the centre, or what
+    // the tier's ray length allows)
+    auto widened = [&](const float4 &sp, const double dk) {
+        double B = near + std::fabs(sp.x - cen[0]) + std::fabs(sp.y - cen[1]) + std::fabs(sp.z - cen[2]);
+        if (std::isfinite(dk)) B = std::min(B, (dk * (1.0 + 1e-6) + std::sqrt((double)sp.w)) * (1.0 + 2e-3));
         return (std::sqrt((double)sp.w + 28.6 * u24 * B * B) + 8.0 * u24 * B) * (1.0 + 1e-9);
     };
     const auto cones = face_cones(n);
     const int leaf_level = (int)cones.size() - 1;
     const size_t cells_per_light = (size_t)6 * n * n;
-    out.lt_cells.assign(nl * cells_per_light, uint2{0u, 0u});
+    out.lt_cells.assign(tiers * nl * cells_per_light, uint2{0u, 0u});
 
     struct PerLight {
         std::vector<uint32_t> cell, sphere;   // (bin, sphere) pairs in the order found
         std::vector<float> reach;             // per sphere: lower bound of the distance light -> widened sphere
         bool failed = false;
     };
-    std::vector<PerLight> per(nl);
-    auto one_light = [&](size_t l) {
+    std::vector<PerLight> per(tiers * nl);   // (tier, light) = per[tier * nl + light]
+    auto one_light = [&](size_t job) {
         try {
-            PerLight &pl = per[l];
+            PerLight &pl = per[job];
+            const size_t l = job % nl;
+            const double dk = tier_d[job / nl];
             const float4 lp = out.light_pos[l];
             const double L[3] = {lp.x, lp.y, lp.z};
-            const double Dmax = near + std::fabs(L[0] - cen[0]) + std::fabs(L[1] - cen[1]) + std::fabs(L[2] - cen[2]);
+            const double Dmax = std::min(near + std::fabs(L[0] - cen[0]) + std::fabs(L[1] - cen[1]) + std::fabs(L[2] - cen[2]),
+                                         dk * (1.0 + 1e-6));
             const double m = 4e-3 * Dmax, dl = 4e-7 * Dmax;
             std::vector<uint32_t> stack;
             // Spheres in the order of how close they come to the light, so that every bin's list
@@ -640,15 +683,16 @@ void build_light_tables(PackedScene &out)
                 const float4 &sp = out.sph[i];
                 if (!usable_sphere(sp)) continue;
                 const double dx = sp.x - L[0], dy = sp.y - L[1], dz = sp.z - L[2];
-                const double reach = std::sqrt(dx * dx + dy * dy + dz * dz) - widened(sp) - dl;
+                const double reach = std::sqrt(dx * dx + dy * dy + dz * dz) - widened(sp, dk) - dl;
                 // rounded down; a ray of length `distance` can only meet spheres with reach <= distance
                 pl.reach[i] = std::isfinite(reach) ? std::nextafter((float)(reach - 1e-6 * std::fabs(reach)), -INFINITY) : -INFINITY;
+                if ((double)pl.reach[i] > dk) continue;   // no ray of this tier is that long
                 by_reach.push_back((uint32_t)i);
             }
             std::stable_sort(by_reach.begin(), by_reach.end(), [&](uint32_t a, uint32_t b) { return pl.reach[a] < pl.reach[b]; });
             for (const uint32_t i : by_reach) {
                 const float4 &sp = out.sph[i];
-                const double R = widened(sp);
+                const double R = widened(sp, dk);
                 const double dx = sp.x - L[0], dy = sp.y - L[1], dz = sp.z - L[2];
                 const double dist = std::sqrt(dx * dx + dy * dy + dz * dz);
                 double cosa = 1.0, sina = 0.0;
@@ -695,14 +739,15 @@ void build_light_tables(PackedScene &out)
                 }
             }
         } catch (...) {
-            per[l].failed = true;
+            per[job].failed = true;
         }
     };
-    // One host thread per light, a few at a time.
-    const size_t workers = std::max<size_t>(1, std::min<size_t>({nl, (size_t)std::thread::hardware_concurrency(), 16}));
-    for (size_t l0 = 0; l0 < nl; l0 += workers) {
+    // One host thread per (tier, light), a few at a time.
+    const size_t jobs = tiers * nl;
+    const size_t workers = std::max<size_t>(1, std::min<size_t>({jobs, (size_t)std::thread::hardware_concurrency(), 16}));
+    for (size_t l0 = 0; l0 < jobs; l0 += workers) {
         std::vector<std::thread> pool;
-        for (size_t l = l0; l < std::min(nl, l0 + workers); l++) pool.emplace_back(one_light, l);
+        for (size_t l = l0; l < std::min(jobs, l0 + workers); l++) pool.emplace_back(one_light, l);
         for (std::thread &t : pool) t.join();
     }
     for (const PerLight &pl : per)
@@ -715,7 +760,7 @@ void build_light_tables(PackedScene &out)
     out.lt_orig.assign(total + RT_LT_PAD, INT_MAX);
     out.lt_reach.assign(total + RT_LT_PAD, INFINITY);
     size_t base = 0;
-    for (size_t l = 0; l < nl; l++) {
+    for (size_t l = 0; l < jobs; l++) {
         const PerLight &pl = per[l];
         uint2 *cells = out.lt_cells.data() + l * cells_per_light;
         for (uint32_t c : pl.cell) cells[c].y++;
@@ -736,6 +781,11 @@ void build_light_tables(PackedScene &out)
     }
     out.lt_n = n;
     out.lt_near = (float)(near * (1.0 - 1e-6));
+    out.lt_tiers = (int)tiers;
+    for (size_t k = 0; k + 1 < tiers; k++) {
+        // (rounded down; the kernel's |o - L|^2 and the square of the reference's `distance` differ by a few ulp)
+        out.lt_tier_q[k] = std::nextafter((float)(tier_d[k] * tier_d[k] * (1.0 - 1e-5)), 0.0f);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1038,6 +1088,8 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     if ((rc = upload(ctx, d, ps.lt_reach, &sc.lt_reach)) != RT_OK) return rc;
     sc.lt_n = ps.lt_n;
     sc.lt_near = ps.lt_near;
+    sc.lt_tiers = ps.lt_tiers;
+    for (int k = 0; k < RT_LT_TIERS - 1; k++) sc.lt_tier_q[k] = ps.lt_tier_q[k];
     if ((rc = upload(ctx, d, ps.gr_cells, &sc.gr_cells)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.gr_sph, &sc.gr_sph)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.gr_orig, &sc.gr_orig)) != RT_OK) return rc;
@@ -1356,6 +1408,8 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     const int light_below_env = light_below_str ? atoi(light_below_str) : -1;
     const int nl = d.scene.nl;
     fr.light_waves = fused || nl < 3 || light_below_env == 0 ? 0 : nl >= 12 ? 16 : nl >= 6 ? 8 : 4;
+    if (const char *e = getenv("RT_HIP_LIGHT_WAVES"))   // tuning aid: waves per workgroup of k_shade_lights
+        if (fr.light_waves && atoi(e) >= 1 && atoi(e) <= 16) fr.light_waves = atoi(e);
     // (The more lights, the longer the queues it pays for: a wave of k_shade_lights looks one light up for 64
     // neighbouring records - one table, nearby cells - where a lane of k_plain goes through all the tables.
     // 16 lights: 4.04 ms per frame with queues below 64 K records, 3.88 below 256 K, 3.64 below 512 K or 1 M, 4.3 for all.)

@@ -47,6 +47,8 @@
 // k1 = 1 - 2^-18, the filter's relative margin (shared by the host's W and the kernels).
 #define RT_FILTER_K1 0.999996185302734375f
 
+#define RT_LT_TIERS 4   // at most so many tiers of the lights' tables (DevScene::lt_tiers)
+
 struct DevScene {
     int ns, np, nt, nl, nprims;
     int ns_padded;
@@ -84,6 +86,11 @@ struct DevScene {
     // + u] = {first entry, entries} of the spheres that can occlude such a ray: lt_sph {centre, r*r}
     // and lt_orig (host primitive index) per entry.  Valid for origins with |o - sph_center|_1 <=
     // lt_near; lt_n = 0: no tables (no spheres or no lights).
+    // The tables come in lt_tiers tiers by the ray's length: tier t (all lights' tables of tier t follow those
+    // of tier t - 1 in lt_cells) holds what can occlude a ray whose squared length |origin - light|^2, as the
+    // kernel forms it, is at most lt_tier_q[t]; the last tier has no such bound.  The reference's rounding
+    // errors grow with the distance between a ray's origin and a sphere, and so does the margin a sphere is
+    // listed with: short rays get short lists.
     const uint2 *lt_cells;
     const float4 *lt_sph;
     const int *lt_orig;
@@ -91,6 +98,8 @@ struct DevScene {
                               // (widened) sphere; a cell's entries are sorted by it
     int lt_n;
     float lt_near;
+    int lt_tiers;
+    float lt_tier_q[RT_LT_TIERS - 1];
     // Uniform grid over the spheres (rt_api.cpp, build_sphere_grid; rt_kernels.hip, "Grid walk"): cell
     // (x, y, z) = gr_cells[(z * gr_n[1] + y) * gr_n[0] + x] = {first entry, entries} of the spheres whose
     // widened ball touches the cell: gr_sph {centre, r*r} and gr_orig (host primitive index) per entry.  The

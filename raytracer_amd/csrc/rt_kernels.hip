@@ -1435,7 +1435,11 @@ __device__ __forceinline__ uint2 light_table_cell(const DevScene &s, const int l
     const int top = s.lt_n - 1;
     const int iu = !(fu >= 0.0f) ? 0 : (fu >= (float)top ? top : (int)fu);   // NaN -> 0
     const int iv = !(fv >= 0.0f) ? 0 : (fv >= (float)top ? top : (int)fv);
-    return s.lt_cells[((size_t)(l * 6 + face) * (size_t)s.lt_n + (size_t)iv) * (size_t)s.lt_n + (size_t)iu];
+    // The tier of the ray's length: the first whose bound |w|^2 does not exceed (NaN: the last, unbounded one).
+    const float q = (w.x * w.x + w.y * w.y) + w.z * w.z;
+    int tier = 0;
+    while (tier < s.lt_tiers - 1 && !(q <= s.lt_tier_q[tier])) tier++;
+    return s.lt_cells[((size_t)((tier * s.nl + l) * 6 + face) * (size_t)s.lt_n + (size_t)iv) * (size_t)s.lt_n + (size_t)iu];
 }
 
 // One light ray against one sphere: true = Sphere.Intersect (objects.cs:112-121) gives a t in (eps, dist).
