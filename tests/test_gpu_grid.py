@@ -125,6 +125,19 @@ def test_light_terms_ahead_with_many_lights(oracle, monkeypatch, below):
             assert np.array_equal(gpu[rows], _oracle_frames["9 lights"][0][rows]), f"9 lights, profiling {profiling}"
 
 
+@pytest.mark.parametrize("knobs", [{"RT_HIP_LIGHT_TIERS": "1"}, {"RT_HIP_LIGHT_TIER_D1": "0.4", "RT_HIP_LIGHT_TIER_RATIO": "2.2"},
+                                   {"RT_HIP_LIGHT_TIER_D1": "2.5", "RT_HIP_LIGHT_TIER_RATIO": "1.15"}])
+def test_any_tiering_of_the_lights_tables_gives_the_same_frame(oracle, monkeypatch, knobs):
+    """The lights' tables are built in tiers by the light ray's length (a short ray's table lists the spheres with
+    a smaller rounding margin): one tier only, tiers so short that most rays fall into the later ones (0.4, 0.88,
+    1.9), tiers close together (2.5, 2.9, 3.3: neighbouring lanes keep changing tier)."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    cam = Camera(position=(0.3, -0.4, -0.5), direction=(0.1, -0.05, 1.0))
+    frames_equal_oracle(oracle, scene_1k().flatten(), cam, 256, 144, 4, f"1k spheres, {knobs}", key="1k")
+    frames_equal_oracle(oracle, scene_64k().flatten(), Camera(), 96, 54, 8, f"64k spheres, {knobs}", key="64k")
+
+
 def test_adversarial_scenes_with_the_grid(oracle):
     """The scenes of test_gpu_adversarial.py (a few hundred spheres each: by itself the library would not
     build a grid for them) with the grid forced: large offsets and scales, tangent pencils, a far camera,
