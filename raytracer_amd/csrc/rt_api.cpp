@@ -299,6 +299,7 @@ struct PackedScene {
     float lt_near = 0.f;
     int lt_tiers = 0;
     float lt_tier_q[RT_LT_TIERS - 1] = {};
+    float gr_tier_t = -1.0f;
     // Uniform grid over the spheres (build_sphere_grid).
     std::vector<uint2> gr_cells;
     std::vector<float4> gr_sph;
@@ -836,6 +837,7 @@ void build_sphere_grid(PackedScene &out)
     out.gr_sph.clear();
     out.gr_orig.clear();
     out.gr_n[0] = out.gr_n[1] = out.gr_n[2] = 0;
+    out.gr_tier_t = -1.0f;
     // Scenes whose spheres fit one LDS chunk keep the kernels that stage it: their wave-wide culling costs fewer
     // instructions per ray than one walk per lane, and a frame is bound by the instructions it issues (1000
     // spheres, 3840x2160: 0.595 ms per frame against 0.616 with the grid; 256x256: 0.16 against 0.20), while
@@ -874,13 +876,30 @@ void build_sphere_grid(PackedScene &out)
         B2 += span * span;
     }
     const double Bmax = std::sqrt(B2) * (1.0 + 1e-6);
-    auto widened = [&](const float4 &sp) {
-        return (std::sqrt((double)sp.w + 28.6 * u24 * Bmax * Bmax) + 8.0 * u24 * Bmax) * (1.0 + 1e-6) + 1e-6 * Bmax;
+    // Two sets of lists over the same cells.  The second serves the cells a ray leaves at a parameter of at
+    // most d1: a hit the reference accepts there lies no farther than d1 (1 + 1e-6) from the origin, so the
+    // origin is at most (d1 (1 + 1e-6) + r_i) (1 + 2e-3) from the centre (build_light_tables, "Tiers": the
+    // same argument with the reflection ray's unit direction), and with that B instead of the region's the
+    // widened ball of a small sphere is barely larger than the sphere (r = 0.0175: 1.05 r against 1.8 r).
+    // d1 = 240 times the median radius; no second set when that reaches the region's bound.
+    // RT_HIP_GRID_TIER_D1 (tuning aid): d1 itself; 0 = no second set.
+    double d1 = 0.0;
+    {
+        std::vector<float> radii;
+        for (const uint32_t i : use) radii.push_back(std::sqrt(out.sph[i].w));
+        std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+        const char *d1_env = getenv("RT_HIP_GRID_TIER_D1");
+        d1 = d1_env ? atof(d1_env) : 240.0 * (double)radii[radii.size() / 2];
+        if (!(d1 > 0.0) || !(d1 < 0.9 * Bmax)) d1 = 0.0;
+    }
+    auto widened = [&](const float4 &sp, const double dk) {
+        const double B = dk > 0.0 ? std::min(Bmax, (dk * (1.0 + 1e-6) + std::sqrt((double)sp.w)) * (1.0 + 2e-3)) : Bmax;
+        return (std::sqrt((double)sp.w + 28.6 * u24 * B * B) + 8.0 * u24 * B) * (1.0 + 1e-6) + 1e-6 * B;
     };
     double glo[3] = {INFINITY, INFINITY, INFINITY}, ghi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (const uint32_t i : use) {
         const float4 &sp = out.sph[i];
-        const double R = widened(sp), c[3] = {sp.x, sp.y, sp.z};
+        const double R = widened(sp, 0.0), c[3] = {sp.x, sp.y, sp.z};
         for (int k = 0; k < 3; k++) glo[k] = std::min(glo[k], c[k] - R), ghi[k] = std::max(ghi[k], c[k] + R);
     }
     double vol = 1.0, side[3];
@@ -905,13 +924,14 @@ void build_sphere_grid(PackedScene &out)
         if (((double)ghi[k] - (double)lo_f[k]) * (double)ih_f[k] > (double)n[k] - 0.005) return;   // (cannot happen)
     }
     const size_t ncells = (size_t)n[0] * n[1] * n[2];
-    // Cell ranges of the boxes.
+    const size_t sets = d1 > 0.0 ? 2 : 1;
+    // Cell ranges of the boxes (those of the region's B: the second set's boxes lie inside them).
     struct Range { int a[3], b[3]; };
     std::vector<Range> ranges(use.size());
     size_t total = 0;
     for (size_t j = 0; j < use.size(); j++) {
         const float4 &sp = out.sph[use[j]];
-        const double R = widened(sp), c[3] = {sp.x, sp.y, sp.z};
+        const double R = widened(sp, 0.0), c[3] = {sp.x, sp.y, sp.z};
         size_t cover = 1;
         for (int k = 0; k < 3; k++) {
             const double a = ((c[k] - R) - (double)lo_f[k]) * (double)ih_f[k] - GRID_EPS;
@@ -923,18 +943,18 @@ void build_sphere_grid(PackedScene &out)
         if (cover > 4096) return;   // a sphere far larger than the cells: the lists would be the scene
         total += cover;
     }
-    if (total > 64 * use.size() + 4096 || total >= ((size_t)1 << 30)) return;
-    out.gr_cells.assign(ncells, uint2{0u, 0u});
+    if (total > 64 * use.size() + 4096 || sets * total >= ((size_t)1 << 30)) return;
+    out.gr_cells.assign(sets * ncells, uint2{0u, 0u});
     auto cell_of = [&](int x, int y, int z) { return ((size_t)z * n[1] + y) * n[0] + x; };
     // Of the cells its box covers a sphere is listed in those that come within R (+ the walk's GRID_EPS cells, as
     // a distance) of its centre: the corners of the box do not.
     double eps_len = 0.0;
     for (int k = 0; k < 3; k++) eps_len = std::max(eps_len, GRID_EPS / (double)ih_f[k]);
     eps_len *= 1.7321;
-    auto for_cells = [&](size_t j, auto &&visit) {
+    auto for_cells = [&](size_t set, size_t j, auto &&visit) {
         const Range &r = ranges[j];
         const float4 &sp = out.sph[use[j]];
-        const double R = widened(sp) + eps_len, c[3] = {sp.x, sp.y, sp.z};
+        const double R = widened(sp, set == 0 ? 0.0 : d1) + eps_len, c[3] = {sp.x, sp.y, sp.z};
         double gap2[3][RT_GRID_MAX_AXIS];   // per axis and cell of the range: squared distance of the centre from the cell's slab
         for (int k = 0; k < 3; k++)
             for (int i = r.a[k]; i <= r.b[k]; i++) {
@@ -946,9 +966,10 @@ void build_sphere_grid(PackedScene &out)
         for (int z = r.a[2]; z <= r.b[2]; z++)
             for (int y = r.a[1]; y <= r.b[1]; y++)
                 for (int x = r.a[0]; x <= r.b[0]; x++)
-                    if (gap2[0][x] + gap2[1][y] + gap2[2][z] <= R2) visit(out.gr_cells[cell_of(x, y, z)]);
+                    if (gap2[0][x] + gap2[1][y] + gap2[2][z] <= R2) visit(out.gr_cells[set * ncells + cell_of(x, y, z)]);
     };
-    for (size_t j = 0; j < use.size(); j++) for_cells(j, [](uint2 &c) { c.y++; });
+    for (size_t set = 0; set < sets; set++)
+        for (size_t j = 0; j < use.size(); j++) for_cells(set, j, [](uint2 &c) { c.y++; });
     // Every list starts at an even entry (the kernel loads its entries in pairs); the gaps and the
     // arrays' ends hold entries that can never be hit.
     size_t off = 0;
@@ -963,12 +984,15 @@ void build_sphere_grid(PackedScene &out)
     }
     out.gr_sph.assign(off + RT_GRID_PAD, float4{0.f, 0.f, 0.f, -INFINITY});
     out.gr_orig.assign(off + RT_GRID_PAD, INT32_MAX);
-    for (size_t j = 0; j < use.size(); j++)
-        for_cells(j, [&](uint2 &c) {
-            out.gr_sph[(size_t)c.x + c.y] = out.sph[use[j]];
-            out.gr_orig[(size_t)c.x + c.y] = out.sph_orig[use[j]];
-            c.y++;
-        });
+    for (size_t set = 0; set < sets; set++)
+        for (size_t j = 0; j < use.size(); j++)
+            for_cells(set, j, [&](uint2 &c) {
+                out.gr_sph[(size_t)c.x + c.y] = out.sph[use[j]];
+                out.gr_orig[(size_t)c.x + c.y] = out.sph_orig[use[j]];
+                c.y++;
+            });
+    // (rounded down; the walk compares the parameter at which the ray leaves a cell with it)
+    out.gr_tier_t = d1 > 0.0 ? std::nextafter((float)(d1 * (1.0 - 1e-5)), 0.0f) : -1.0f;
     for (int k = 0; k < 3; k++) {
         out.gr_n[k] = n[k];
         out.gr_lo[k] = lo_f[k];
@@ -1111,6 +1135,7 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     if ((rc = upload(ctx, d, ps.gr_cells, &sc.gr_cells)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.gr_sph, &sc.gr_sph)) != RT_OK) return rc;
     if ((rc = upload(ctx, d, ps.gr_orig, &sc.gr_orig)) != RT_OK) return rc;
+    sc.gr_tier_t = ps.gr_tier_t;
     for (int k = 0; k < 3; k++) {
         sc.gr_n[k] = ps.gr_n[k];
         sc.gr_lo[k] = ps.gr_lo[k];

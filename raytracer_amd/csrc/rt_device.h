@@ -105,9 +105,12 @@ struct DevScene {
     // widened ball touches the cell: gr_sph {centre, r*r} and gr_orig (host primitive index) per entry.  The
     // lists hold every sphere the reference can accept for a ray whose ORIGIN lies in the box gr_reg_lo ..
     // gr_reg_hi; other origins evaluate every sphere.  gr_n[0] = 0: no grid.
+    // gr_tier_t >= 0: a second set of lists follows the first in gr_cells (cell + gr_n[0] * gr_n[1] * gr_n[2]),
+    // shorter ones, good for the cells a ray leaves at a parameter of at most gr_tier_t.
     const uint2 *gr_cells;
     const float4 *gr_sph;
     const int *gr_orig;
+    float gr_tier_t;
     int gr_n[3];
     float gr_lo[3];           // the grid's lower corner
     float gr_ih[3];           // cells per unit of length

@@ -2341,7 +2341,8 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
     const int lane = threadIdx.x & 63;
     if (threadIdx.x == 0) G.next = 0u;
     __syncthreads();
-    const int n0 = s.gr_n[0], n1 = s.gr_n[1], n2 = s.gr_n[2];
+    const int n0 = s.gr_n[0], n1 = s.gr_n[1], n2 = s.gr_n[2], ncells = n0 * n1 * n2;
+    float leave = 0.f;   // parameter at which the ray leaves its current cell
     int state = GRID_EMPTY, my = 0, left = 0, cell = 0;
     unsigned e = 0u, end = 0u;
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
@@ -2436,7 +2437,8 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
                             tmx = ddx == 0.0f ? RT_FLT_MAX : ((float)(ix + (rx > 0.0f ? 1 : 0)) - gx) * rx;
                             tmy = ddy == 0.0f ? RT_FLT_MAX : ((float)(iy + (ry > 0.0f ? 1 : 0)) - gy) * ry;
                             tmz = ddz == 0.0f ? RT_FLT_MAX : ((float)(iz + (rz > 0.0f ? 1 : 0)) - gz) * rz;
-                            const uint2 cur = s.gr_cells[(iz * n1 + iy) * n0 + ix];
+                            leave = fminf(fminf(tmx, tmy), tmz);
+                            const uint2 cur = s.gr_cells[(iz * n1 + iy) * n0 + ix + (leave <= s.gr_tier_t ? ncells : 0)];
                             e = cur.x, end = cur.x + cur.y;
                             left = n0 + n1 + n2 + 3;   // (a ray of NaNs must end too)
                             cells++;
@@ -2465,7 +2467,6 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
                 tests += 2;
             }
             if (e >= end) {
-                const float leave = fminf(fminf(tmx, tmy), tmz);
                 const bool bx = tmx <= tmy && tmx <= tmz, by = !bx && tmy <= tmz;
                 int ix = cell & 1023, iy = (cell >> 10) & 1023, iz = cell >> 20;
                 if (bx) ix += rx > 0.0f ? 1 : -1;
@@ -2476,11 +2477,13 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
                     state = GRID_FINISHED;
                 } else {
                     cell = ix | (iy << 10) | (iz << 20);
-                    const uint2 cur = s.gr_cells[(iz * n1 + iy) * n0 + ix];
-                    e = cur.x, end = cur.x + cur.y;
                     if (bx) tmx = ((float)(ix + (rx > 0.0f ? 1 : 0)) - gx) * rx;
                     else if (by) tmy = ((float)(iy + (ry > 0.0f ? 1 : 0)) - gy) * ry;
                     else tmz = ((float)(iz + (rz > 0.0f ? 1 : 0)) - gz) * rz;
+                    // (the short lists while the ray leaves the cell early enough: rt_device.h, gr_tier_t)
+                    leave = fminf(fminf(tmx, tmy), tmz);
+                    const uint2 cur = s.gr_cells[(iz * n1 + iy) * n0 + ix + (leave <= s.gr_tier_t ? ncells : 0)];
+                    e = cur.x, end = cur.x + cur.y;
                     cells++;
                 }
             }

@@ -38,11 +38,13 @@ def frames_equal_oracle(oracle, fs, cam, w, h, depth, what, row_step=1, key=None
 
 
 @pytest.mark.parametrize("knob,value", [("RT_HIP_GRID", "0"), ("RT_HIP_GRID_DENSITY", "0.05"), ("RT_HIP_GRID_DENSITY", "64"),
-                                        ("RT_HIP_GRID_REGION", "0"), ("RT_HIP_GRID_REGION", "8")])
+                                        ("RT_HIP_GRID_REGION", "0"), ("RT_HIP_GRID_REGION", "8"),
+                                        ("RT_HIP_GRID_TIER_D1", "0"), ("RT_HIP_GRID_TIER_D1", "0.3"), ("RT_HIP_GRID_TIER_D1", "1.5")])
 def test_any_grid_gives_the_same_frame(oracle, monkeypatch, knob, value):
     """No grid at all, one cell per twenty spheres, 64 cells per sphere, a served region that ends at
     the spheres' own extent (most reflection rays then start outside it and evaluate every sphere, in
-    the same waves as rays that walk the grid), one that reaches far beyond the room."""
+    the same waves as rays that walk the grid), one that reaches far beyond the room; without the second, shorter
+    set of lists for the near part of a walk, with one that ends after 0.3 or 1.5 units of length."""
     cam = Camera(position=(0.3, -0.4, -0.5), direction=(0.1, -0.05, 1.0))
     fs1, fs64 = scene_1k().flatten(), scene_64k().flatten()
     base1 = frames_equal_oracle(oracle, fs1, cam, 256, 144, 4, "1k spheres, default grid", key="1k")
