@@ -2458,6 +2458,29 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
         // spheres, so that moving on and testing is one fetch - empty cells then cost two tests each.  The
         // loop is bound by the instructions it issues, not by the latency of its loads.)
         if (state == GRID_WALKING) {
+            // When this step ends the cell's list, the next cell's word is fetched BEFORE the entries are
+            // looked at, so that the two loads are in flight together (a walk is a chain of dependent loads,
+            // and the deep levels of a frame are as long as their longest walk); whether the walk goes on is
+            // only known after the entries, and a word fetched in vain is dropped.
+            const bool last = e + 2u >= end;
+            int ncell = 0;
+            float ntm = 0.f, nleave = 0.f;
+            bool bx = false, by = false, inside = false;
+            uint2 nxt = make_uint2(0u, 0u);
+            if (last) {
+                bx = tmx <= tmy && tmx <= tmz, by = !bx && tmy <= tmz;
+                int ix = cell & 1023, iy = (cell >> 10) & 1023, iz = cell >> 20;
+                if (bx) ix += rx > 0.0f ? 1 : -1;
+                else if (by) iy += ry > 0.0f ? 1 : -1;
+                else iz += rz > 0.0f ? 1 : -1;
+                inside = (unsigned)ix < (unsigned)n0 && (unsigned)iy < (unsigned)n1 && (unsigned)iz < (unsigned)n2;
+                ncell = ix | (iy << 10) | (iz << 20);
+                if (bx) ntm = ((float)(ix + (rx > 0.0f ? 1 : 0)) - gx) * rx, nleave = fminf(fminf(ntm, tmy), tmz);
+                else if (by) ntm = ((float)(iy + (ry > 0.0f ? 1 : 0)) - gy) * ry, nleave = fminf(fminf(tmx, ntm), tmz);
+                else ntm = ((float)(iz + (rz > 0.0f ? 1 : 0)) - gz) * rz, nleave = fminf(fminf(tmx, tmy), ntm);
+                // (the short lists while the ray leaves the cell early enough: rt_device.h, gr_tier_t)
+                if (inside) nxt = s.gr_cells[(iz * n1 + iy) * n0 + ix + (nleave <= s.gr_tier_t ? ncells : 0)];
+            }
             if (e < end) {
                 const float4 s0 = s.gr_sph[e], s1 = s.gr_sph[e + 1];
                 const int2 og = *reinterpret_cast<const int2 *>(&s.gr_orig[e]);
@@ -2466,24 +2489,16 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
                 e += 2u;
                 tests += 2;
             }
-            if (e >= end) {
-                const bool bx = tmx <= tmy && tmx <= tmz, by = !bx && tmy <= tmz;
-                int ix = cell & 1023, iy = (cell >> 10) & 1023, iz = cell >> 20;
-                if (bx) ix += rx > 0.0f ? 1 : -1;
-                else if (by) iy += ry > 0.0f ? 1 : -1;
-                else iz += rz > 0.0f ? 1 : -1;
-                const bool inside = (unsigned)ix < (unsigned)n0 && (unsigned)iy < (unsigned)n1 && (unsigned)iz < (unsigned)n2;
+            if (last) {
                 if (best.hi < leave || !inside || --left <= 0) {
                     state = GRID_FINISHED;
                 } else {
-                    cell = ix | (iy << 10) | (iz << 20);
-                    if (bx) tmx = ((float)(ix + (rx > 0.0f ? 1 : 0)) - gx) * rx;
-                    else if (by) tmy = ((float)(iy + (ry > 0.0f ? 1 : 0)) - gy) * ry;
-                    else tmz = ((float)(iz + (rz > 0.0f ? 1 : 0)) - gz) * rz;
-                    // (the short lists while the ray leaves the cell early enough: rt_device.h, gr_tier_t)
-                    leave = fminf(fminf(tmx, tmy), tmz);
-                    const uint2 cur = s.gr_cells[(iz * n1 + iy) * n0 + ix + (leave <= s.gr_tier_t ? ncells : 0)];
-                    e = cur.x, end = cur.x + cur.y;
+                    cell = ncell;
+                    if (bx) tmx = ntm;
+                    else if (by) tmy = ntm;
+                    else tmz = ntm;
+                    leave = nleave;
+                    e = nxt.x, end = nxt.x + nxt.y;
                     cells++;
                 }
             }
