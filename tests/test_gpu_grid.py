@@ -140,12 +140,18 @@ def test_any_tiering_of_the_lights_tables_gives_the_same_frame(oracle, monkeypat
     frames_equal_oracle(oracle, scene_64k().flatten(), Camera(), 96, 54, 8, f"64k spheres, {knobs}", key="64k")
 
 
-def test_adversarial_scenes_with_the_grid(oracle):
+@pytest.mark.parametrize("knobs", [{}, {"RT_HIP_LIGHT_TIER_D1": "0.5", "RT_HIP_LIGHT_TIER_RATIO": "2", "RT_HIP_GRID_TIER_D1": "0.7"}])
+def test_adversarial_scenes_with_the_grid(oracle, monkeypatch, knobs):
     """The scenes of test_gpu_adversarial.py (a few hundred spheres each: by itself the library would not
     build a grid for them) with the grid forced: large offsets and scales, tangent pencils, a far camera,
-    degenerate spheres, lights and cameras, hit points far outside the served region."""
+    degenerate spheres, lights and cameras, hit points far outside the served region.  Once as the library
+    builds its tables for them, once with tiers of the lights' tables at ray lengths of 0.5, 1 and 2 and the
+    grid's short lists up to 0.7, whatever the scene's scale (a hundred times larger: nearly every ray is
+    longer than every tier; fifty times smaller: the region's own bound is the tighter one)."""
     import importlib.util
     import os
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
     spec = importlib.util.spec_from_file_location("adversarial_scenes", os.path.join(os.path.dirname(__file__), "test_gpu_adversarial.py"))
     adv = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(adv)
