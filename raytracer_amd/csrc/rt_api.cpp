@@ -1512,7 +1512,6 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     fr.lit = nullptr;
     {
         const char *early_env = getenv("RT_HIP_EARLY_LIGHTS");
-        const size_t want = (size_t)fr.P * (size_t)max_depth * (size_t)std::max(nl, 1);
         // (not for a context that shares its device with others rendering at the same time: there the
         // tail of one frame is filled by the other frames' kernels anyway, and the extra traffic costs 5 %)
         // With more than four lights only for the levels of few reflecting records: their passes at the end of
@@ -1523,6 +1522,9 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
         const char *lit_lights_env = getenv("RT_HIP_EARLY_LIGHTS_MAX"), *lit_below_env = getenv("RT_HIP_EARLY_LIGHTS_BELOW");
         const int lit_lights = lit_lights_env ? atoi(lit_lights_env) : 16;
         fr.lit_below = nl <= 4 ? 0 : lit_below_env ? atoi(lit_below_env) : 65536;
+        // (a level with its terms ahead holds fewer than lit_below reflecting records)
+        fr.lit_stride = fr.lit_below > 0 ? std::min(fr.P, fr.lit_below) : fr.P;
+        const size_t want = (size_t)fr.lit_stride * (size_t)max_depth * (size_t)std::max(nl, 1);
         if (!fused && !fixed_scratch && share == 1 && max_depth > 0 && nl >= 1 && nl <= lit_lights &&
             (!early_env || atoi(early_env) != 0) &&
             want * sizeof(float4) <= RT_LIT_MAX_BYTES) {

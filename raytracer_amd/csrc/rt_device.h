@@ -230,6 +230,7 @@ struct DevFrame {
     // levels below max_depth and per light {what the light adds directly (rgb), distance * distance}.
     // Null: k_shade runs the whole light loop itself.
     float4 *lit;
+    int lit_stride;        // records per level that lit has room for
     int lit_below;         // > 0: only for levels of fewer than that many reflecting records (the others run their
                            // whole light loop once their children are shaded)
     int light_waves;       // > 0: queues of fewer than light_split_below records are shaded with the lights spread

@@ -1824,9 +1824,16 @@ __device__ __forceinline__ void shade_record(const DevScene &s, const DevFrame &
 // path) and kept in DevFrame::lit; once the child's colour is there only the sum is left
 // (combine_record): the same additions in the same order as shade_record makes them.  Every lane of
 // the wave must call lit_record.
+// Where DevFrame::lit keeps the light terms of the reflecting record in `slot` of `level` (lit_stride records
+// per level: with many lights only the short queues have their terms computed ahead).
+__device__ __forceinline__ size_t lit_first(const DevFrame &f, const int level, const int slot, const int nl)
+{
+    return ((size_t)level * (size_t)f.lit_stride + (size_t)(slot - level * f.P)) * (size_t)nl;
+}
+
 template <bool COUNT>
-__device__ __forceinline__ void lit_record(const DevScene &s, const DevFrame &f, const int slot, const bool active,
-                                           TestCount &tc)
+__device__ __forceinline__ void lit_record(const DevScene &s, const DevFrame &f, const int level, const int slot,
+                                           const bool active, TestCount &tc)
 {
     const ShadeRecord r = shade_setup(s, f, slot, active, false, false);
     const int nl = s.nl;
@@ -1838,7 +1845,7 @@ __device__ __forceinline__ void lit_record(const DevScene &s, const DevFrame &f,
         f3 reflected, direct;
         float d2;
         light_terms<COUNT>(s, r, l, cell, active, tc, reflected, direct, d2);
-        if (active) f.lit[(size_t)slot * (size_t)nl + (size_t)l] = make_float4(direct.x, direct.y, direct.z, d2);
+        if (active) f.lit[lit_first(f, level, slot, nl) + (size_t)l] = make_float4(direct.x, direct.y, direct.z, d2);
     }
 }
 
@@ -1853,7 +1860,7 @@ __device__ __forceinline__ void combine_record(const DevScene &s, const DevFrame
     f3 final = mk3(0.0f, 0.0f, 0.0f);
     const int nl = s.nl;
     for (int l = 0; l < nl; l++) {
-        const float4 t = f.lit[(size_t)slot * (size_t)nl + (size_t)l];
+        const float4 t = f.lit[lit_first(f, level, slot, nl) + (size_t)l];
         if (have_refl) final = add3(final, mk3(ieee_div(refl_term.x, t.w), ieee_div(refl_term.y, t.w), ieee_div(refl_term.z, t.w)));
         final = add3(final, xyz(t));
     }
@@ -2741,7 +2748,7 @@ k_plain_tail(DevScene s, DevFrame f, int level, int level_hi, int32_t *pixels)
             const int ntiles = (na + 255) >> 8;
             for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
                 const int i = tile * 256 + threadIdx.x;
-                lit_record<COUNT>(s, f, lv * f.P + (i < na ? i : na - 1), i < na, tc);
+                lit_record<COUNT>(s, f, lv, lv * f.P + (i < na ? i : na - 1), i < na, tc);
             }
         }
     }
@@ -2761,7 +2768,7 @@ k_lit(DevScene s, DevFrame f, int level)
     TestCount tc = {0, 0, 0, 0, 0, 0, 0};
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int i = tile * 256 + threadIdx.x;
-        lit_record<COUNT>(s, f, level * f.P + (i < n ? i : n - 1), i < n, tc);
+        lit_record<COUNT>(s, f, level, level * f.P + (i < n ? i : n - 1), i < n, tc);
     }
     if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
 }
@@ -3047,7 +3054,7 @@ __global__ void __launch_bounds__(64 * LIGHT_WAVES_MAX) k_shade_lights(DevScene 
                 f3 reflected, direct;
                 float d2;
                 light_terms<COUNT>(s, r, l, cell, active, tc, reflected, direct, d2);
-                if (ahead && active) f.lit[(size_t)slot * (size_t)nl + (size_t)l] = make_float4(direct.x, direct.y, direct.z, d2);
+                if (ahead && active) f.lit[lit_first(f, level, slot, nl) + (size_t)l] = make_float4(direct.x, direct.y, direct.z, d2);
                 terms[wave][0][lane] = reflected.x, terms[wave][1][lane] = reflected.y, terms[wave][2][lane] = reflected.z;
                 terms[wave][3][lane] = direct.x, terms[wave][4][lane] = direct.y, terms[wave][5][lane] = direct.z;
             }
