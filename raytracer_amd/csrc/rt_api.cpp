@@ -115,8 +115,8 @@ struct DeviceState {
     size_t cap_slots = 0;
     // Buffers of the record binning (k_bin_*), sized for one level of the largest frame so far.
     uint2 *bin_aux = nullptr;
-    float4 *bin_tmp_a = nullptr, *bin_tmp_b = nullptr;
     int *bin_hist = nullptr;   // histograms, then the prefix sums: 4 * RT_BINS ints
+    bool spare_level = false;  // the frame's record arrays hold a spare level (ensure_frame)
     size_t cap_bin = 0, bin_refused = SIZE_MAX;
     // Light terms of the reflecting records (DevFrame::lit), for cap_lit float4s.
     float4 *lit = nullptr;
@@ -252,11 +252,8 @@ void free_frame(DeviceState &d)
     if (d.frame.refl) (void)hipFree(d.frame.refl);
     if (d.frame.counters) (void)hipFree(d.frame.counters);   // counters, sched and cnt are one allocation
     if (d.bin_aux) (void)hipFree(d.bin_aux);
-    if (d.bin_tmp_a) (void)hipFree(d.bin_tmp_a);
-    if (d.bin_tmp_b) (void)hipFree(d.bin_tmp_b);
     if (d.bin_hist) (void)hipFree(d.bin_hist);
     d.bin_aux = nullptr;
-    d.bin_tmp_a = d.bin_tmp_b = nullptr;
     d.bin_hist = nullptr;
     d.cap_bin = 0;
     if (d.lit) (void)hipFree(d.lit);
@@ -1268,7 +1265,10 @@ int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth)
     // Level stride: the pixels rounded up so that no cache line of any per-slot array (16-byte
     // records) holds slots of two levels (see k_trace_levels).
     const size_t stride = ((size_t)P + RT_LEVEL_ALIGN - 1) / RT_LEVEL_ALIGN * RT_LEVEL_ALIGN;
-    const size_t slots = stride * (size_t)levels;
+    // Scenes whose deeper levels may be put into bin order (many chunks or many lights) get a spare level behind
+    // the last one, where a level's records are staged until the binning pass moves them to their slots.
+    d.spare_level = max_depth > 0 && (d.scene.ns_padded > RT_CHUNK || d.scene.nl >= 8);
+    const size_t slots = stride * (size_t)(levels + (d.spare_level ? 1 : 0));
     if (slots > (size_t)INT32_MAX)
         return fail(ctx, RT_ERR_LIMIT, "%d pixels x %d levels exceeds 2^31-1 hit-record slots", P, levels);
     if (slots > d.cap_slots) {
@@ -1292,7 +1292,7 @@ int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth)
         d.frame.cnt = reinterpret_cast<int *>(ctl + RT_COUNTER_SLOTS * sizeof(DevCounters) + sizeof(DevSched));
     }
     d.frame.P = (int)stride;
-    d.frame.slots = (int)slots;
+    d.frame.slots = (int)(stride * (size_t)levels);
     d.frame.max_depth = max_depth;
     return RT_OK;
 }
@@ -1463,28 +1463,21 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     const char *bin_min_str = getenv("RT_HIP_BIN_MIN");
     const int bin_min_env = bin_min_str ? atoi(bin_min_str) : -1;
     fr.bin_min = 0;
+    fr.stage_base = 0;
+    fr.staged = 0;
     if (!fused && !fixed_scratch && max_depth > 0 && bin_min_env != 0 && (d.scene.ns_padded > RT_CHUNK || nl >= 8) &&
         d.scene.bin_scale[0] > 0.f) {
         const size_t stride = (size_t)fr.P;
         if (stride > d.cap_bin && stride < d.bin_refused) {
             if (d.bin_aux) (void)hipFree(d.bin_aux);
-            if (d.bin_tmp_a) (void)hipFree(d.bin_tmp_a);
-            if (d.bin_tmp_b) (void)hipFree(d.bin_tmp_b);
             d.bin_aux = nullptr;
-            d.bin_tmp_a = d.bin_tmp_b = nullptr;
             d.cap_bin = 0;
             // An optimisation only: a device that cannot give the memory renders without it.
-            if (hipMalloc((void **)&d.bin_aux, stride * sizeof(uint2)) == hipSuccess &&
-                hipMalloc((void **)&d.bin_tmp_a, stride * sizeof(float4)) == hipSuccess &&
-                hipMalloc((void **)&d.bin_tmp_b, stride * sizeof(float4)) == hipSuccess)
+            if (hipMalloc((void **)&d.bin_aux, stride * sizeof(uint2)) == hipSuccess)
                 d.cap_bin = stride;
             else {
                 (void)hipGetLastError();
-                if (d.bin_aux) (void)hipFree(d.bin_aux);
-                if (d.bin_tmp_a) (void)hipFree(d.bin_tmp_a);
-                if (d.bin_tmp_b) (void)hipFree(d.bin_tmp_b);
                 d.bin_aux = nullptr;
-                d.bin_tmp_a = d.bin_tmp_b = nullptr;
                 d.bin_refused = stride;
             }
         }
@@ -1496,11 +1489,11 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
                 d.bin_hist = nullptr;
             }
         }
-        if (stride <= d.cap_bin && d.bin_hist) {
+        if (stride <= d.cap_bin && d.bin_hist && d.spare_level) {
             fr.bin_min = bin_min_env > 0 ? bin_min_env : 16384;
+            fr.stage_base = (max_depth + 1) * fr.P;   // (the spare level: ensure_frame)
+            fr.staged = grid ? 1 : 0;
             fr.bin_aux = d.bin_aux;
-            fr.bin_tmp_a = d.bin_tmp_a;
-            fr.bin_tmp_b = d.bin_tmp_b;
             fr.bin_hist = d.bin_hist;
             fr.bin_base = d.bin_hist + 2 * RT_BINS;
         }

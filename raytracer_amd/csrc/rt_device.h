@@ -222,8 +222,10 @@ struct DevFrame {
     // traced and shaded (k_bin_*): bin_min > 0 enables it for levels of at least that many records.
     int bin_min;
     uint2 *bin_aux;        // per record of the level being binned: {bin, rank within the bin}
-    float4 *bin_tmp_a;     // the level's records in their new order, before they are copied back
-    float4 *bin_tmp_b;
+    int stage_base;        // frames with bin_min > 0: first slot of a spare level of recA / recB behind the last one,
+                           // what the binning passes move a level's records through
+    int staged;            // 1: the records of a level >= 1 are first written there (laid out like a level; the grid
+                           // walk's launches), and k_bin_scatter moves them to the level's own slots
     int *bin_hist;         // [2 * RT_BINS] records per bin (reflecting queue, plain queue); zero between uses
     int *bin_base;         // [2 * RT_BINS] first position of each bin in its queue
     // Light terms of the reflecting records, computed ahead of their children (k_lit): per slot of the

@@ -233,7 +233,7 @@ __device__ __forceinline__ void load_record(const float4 *a, const float4 *b, fl
 // frame appends hundreds of thousands of waves' worth of records.  Every thread of the
 // workgroup must call it (two barriers inside); blk is a __shared__ int[2 * waves + 2] or larger.
 //   A records (need a reflection trace) fill the level from the front, B records from the back.
-template <int N, bool THROUGH = true>
+template <int N, bool THROUGH = true, bool STAGE = false>
 __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &s, int level, int *blk,
                                              const bool (&valid)[N], const int (&prim)[N], const f3 (&hit)[N],
                                              const f3 (&view)[N], const int (&parent)[N])
@@ -278,10 +278,13 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
     }
     __syncthreads();
     const int base_a = blk[2 * nwaves] + blk[2 * wave], base_b = blk[2 * nwaves + 1] + blk[2 * wave + 1];
+    // STAGE (the grid walk's launches): a frame whose deeper levels are put into bin order stages their records in
+    // a spare level (DevFrame::staged, stage_base); k_bin_scatter moves them to their slots.
+    const int first = STAGE && f.staged && level >= 1 ? f.stage_base : level * f.P;
 #pragma unroll
     for (int k = 0; k < N; k++) {
         if (valid[k]) {
-            const int slot = is_a[k] ? (level * f.P + base_a + off[k]) : ((level + 1) * f.P - 1 - (base_b + off[k]));
+            const int slot = is_a[k] ? (first + base_a + off[k]) : (first + f.P - 1 - (base_b + off[k]));
             // THROUGH: the records are read later in this launch, by other XCDs (device-scope
             // stores); otherwise by a later launch, which sees plain stores.
             if (THROUGH) {
@@ -295,8 +298,9 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
             // closest hit so far in the first two words of the record's refl slot: nothing yet.
             if (f.split_chunks && is_a[k]) {
                 const float none = __uint_as_float(0xffffffffu);
-                if (THROUGH) store_record(&f.refl[slot], f4raw{none, none, 0.0f, 0.0f});
-                else f.refl[slot] = make_float4(none, none, 0.0f, 0.0f);
+                const int own = slot - first + level * f.P;   // (refl is not staged)
+                if (THROUGH) store_record(&f.refl[own], f4raw{none, none, 0.0f, 0.0f});
+                else f.refl[own] = make_float4(none, none, 0.0f, 0.0f);
             }
         }
     }
@@ -2552,7 +2556,7 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
         tc.exact += tests;
         tc.grid += cells;
     }
-    push_records<PER, THROUGH>(f, s, level + 1, blk, rv, rp, rh, rd, rparent);
+    push_records<PER, THROUGH, !THROUGH>(f, s, level + 1, blk, rv, rp, rh, rd, rparent);
 }
 
 #ifndef RT_GRID_WAVES
@@ -2584,8 +2588,9 @@ k_reflect_grid(DevScene s, DevFrame f, int level)
 // tests per ray.  Before a level >= 1 of enough records is used, its records are therefore put
 // into the order of the position bins of their hit points (16 x 16 x 16 cells over the spheres'
 // extent, in Morton order so that consecutive bins are neighbours): count per bin with each
-// record's rank taken from the counting atomic, prefix sums, scatter into a second buffer, copy
-// back.  The order of records changes nothing observable: a record is shaded by itself, children
+// record's rank taken from the counting atomic, prefix sums, scatter into a spare level, copy back.  The grid
+// walk's launches write a level's records to the spare level in the first place (push_records, STAGE), and the
+// scatter moves them to their slots: no pass over the records beyond the one that orders them.  The order of records changes nothing observable: a record is shaded by itself, children
 // are created after the move and name their parents by the new slots, and a record's own parent
 // field moves with it.
 // ---------------------------------------------------------------------------------------
@@ -2604,10 +2609,15 @@ __device__ __forceinline__ int position_bin(const DevScene &s, const f3 p)
     }
     return (int)(spread4(c[0]) | (spread4(c[1]) << 1) | (spread4(c[2]) << 2));
 }
-// Record i of the level's two queues taken together (reflecting first): its slot.
+// Record i of the level's two queues taken together (reflecting first): its slot, and where push_records
+// staged it in the binning passes' buffers.
 __device__ __forceinline__ int binned_slot(const DevFrame &f, const int level, const int na, const int i)
 {
     return i < na ? level * f.P + i : (level + 1) * f.P - 1 - (i - na);
+}
+__device__ __forceinline__ int staged_at(const DevFrame &f, const int na, const int i)
+{
+    return i < na ? i : f.P - 1 - (i - na);
 }
 
 // A workgroup counts a block of BIN_BLOCK records in LDS first and adds each bin it met to the global
@@ -2630,7 +2640,7 @@ __global__ void __launch_bounds__(256) k_bin_count(DevScene s, DevFrame f, int l
             const int i = first + r * 256 + threadIdx.x;
             bin[r] = -1;
             if (i < n) {
-                const float4 ra = f.recA[binned_slot(f, level, na, i)];
+                const float4 ra = f.recA[f.staged ? f.stage_base + staged_at(f, na, i) : binned_slot(f, level, na, i)];
                 bin[r] = (i < na ? 0 : RT_BINS) + position_bin(s, xyz(ra));
                 rank[r] = atomicAdd(&local[bin[r]], 1);
             }
@@ -2687,16 +2697,24 @@ __global__ void __launch_bounds__(1024) k_bin_scan(DevFrame f, int level)
     }
 }
 
+// The level's records into bin order.  Staged records (DevFrame::staged) go from the spare level straight to their
+// slots - as they lie when the level is too short for the order -; others are put into order in the spare level
+// and copied back by k_bin_copy.
 __global__ void __launch_bounds__(256) k_bin_scatter(DevFrame f, int level)
 {
     const int na = f.cnt[2 * level], n = na + f.cnt[2 * level + 1];
-    if (n < f.bin_min) return;
+    const bool in_order = n >= f.bin_min;
+    if (!f.staged && !in_order) return;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint2 a = f.bin_aux[i];
-        const int to = (i < na ? 0 : na) + f.bin_base[a.x] + (int)a.y;   // position among the level's records
-        const int slot = binned_slot(f, level, na, i);
-        f.bin_tmp_a[to] = f.recA[slot];
-        f.bin_tmp_b[to] = f.recB[slot];
+        int to = i;
+        if (in_order) {
+            const uint2 a = f.bin_aux[i];
+            to = (i < na ? 0 : na) + f.bin_base[a.x] + (int)a.y;   // position among the level's records
+        }
+        const int from = f.staged ? f.stage_base + staged_at(f, na, i) : binned_slot(f, level, na, i);
+        const int slot = f.staged ? binned_slot(f, level, na, to) : f.stage_base + to;
+        f.recA[slot] = f.recA[from];
+        f.recB[slot] = f.recB[from];
     }
 }
 
@@ -2706,8 +2724,8 @@ __global__ void __launch_bounds__(256) k_bin_copy(DevFrame f, int level)
     if (n < f.bin_min) return;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int slot = binned_slot(f, level, na, i);
-        f.recA[slot] = f.bin_tmp_a[i];
-        f.recB[slot] = f.bin_tmp_b[i];
+        f.recA[slot] = f.recA[f.stage_base + i];
+        f.recB[slot] = f.recB[f.stage_base + i];
     }
 }
 
@@ -3263,7 +3281,7 @@ void rtk_bin_level(const DevScene &s, const DevFrame &f, int level, int grid_blo
     hipLaunchKernelGGL(k_bin_count, g, b, 0, stream, s, f, level);
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, f, level);
     hipLaunchKernelGGL(k_bin_scatter, g, b, 0, stream, f, level);
-    hipLaunchKernelGGL(k_bin_copy, g, b, 0, stream, f, level);
+    if (!f.staged) hipLaunchKernelGGL(k_bin_copy, g, b, 0, stream, f, level);
 }
 
 void rtk_reflect_chunks(const DevScene &s, const DevFrame &f, int level, int job_blocks, int tile_blocks, hipStream_t stream)
