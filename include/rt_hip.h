@@ -263,8 +263,9 @@ int rt_alloc_pixels(rt_ctx *ctx, int64_t count, int32_t **pixels_out);
  * Device memory: every render entry keeps the frame's ray queues in the context, sized for the
  * worst case (every pixel alive at every level) and grown, never shrunk, when a larger frame
  * comes: 48 bytes * pixels of the call (rounded up to 64) * (max_depth + 1), i.e. 2.0 GB for
- * 3840x2160 at max_depth 4 and 14.3 GB for 7680x4320 at max_depth 8 (scenes of at most four lights:
- * 16 bytes * pixels * max_depth * lights more, for light terms computed ahead); RT_ERR_OUT_OF_MEMORY when
+ * 3840x2160 at max_depth 4 and 14.3 GB for 7680x4320 at max_depth 8 (scenes of more than 1024 spheres or at
+ * least eight lights: one level more; scenes of at most four lights: 16 bytes * pixels * max_depth * lights
+ * more, for light terms computed ahead; more lights: 16 bytes * 65536 * max_depth * lights); RT_ERR_OUT_OF_MEMORY when
  * the device cannot give that.  A rank of a row partition allocates for its own rows only.
  * This is the per-rank entry of the one-process-per-GPU row partition: rank r of
  * G renders its block and the framebuffer blocks are gathered with one
