@@ -140,6 +140,34 @@ def test_any_tiering_of_the_lights_tables_gives_the_same_frame(oracle, monkeypat
     frames_equal_oracle(oracle, scene_64k().flatten(), Camera(), 96, 54, 8, f"64k spheres, {knobs}", key="64k")
 
 
+def test_tiers_change_nothing_on_the_full_size_frames(monkeypatch):
+    """The 64k-sphere, 16-light scene at 1920x1080 with 8 bounces (52 M rays) and three other views of it, as the
+    library builds its tables (four tiers of the lights' tables, two sets of grid lists) and with one tier and one
+    set: the same frames, pixel for pixel, and the same ray counts.  (The untiered tables are the ones the CPU
+    restatement pins at the sizes it can render.)"""
+    fs = scene_64k().flatten()
+    cams = [Camera(), Camera(position=(2.5, -2.0, 0.2), direction=(-0.6, 0.1, 1.0)),
+            Camera(position=(0.0, -3.6, 1.9), direction=(0.0, 1.0, 0.05), fov=70.0),
+            Camera(position=(-3.4, 0.4, 3.3), direction=(1.0, -0.3, -0.6), fov=110.0)]
+
+    def frames():
+        out = []
+        with RenderContext() as c:
+            c.set_scene(fs)
+            for cam in cams:
+                out.append((c.render(cam, 1920, 1080, 8).copy(), c.stats()["rays_shadow"], c.stats()["rays_secondary"]))
+        return out
+
+    tiered = frames()
+    monkeypatch.setenv("RT_HIP_LIGHT_TIERS", "1")
+    monkeypatch.setenv("RT_HIP_GRID_TIER_D1", "0")
+    plain = frames()
+    for k, ((a, sa, ra), (b, sb, rb)) in enumerate(zip(tiered, plain)):
+        assert (sa, ra) == (sb, rb), f"view {k}: ray counts differ"
+        assert np.array_equal(a, b), f"view {k}: {np.count_nonzero(a != b)} pixels differ"
+        assert len(np.unique(a)) > 1000   # a real picture
+
+
 @pytest.mark.parametrize("knobs", [{}, {"RT_HIP_LIGHT_TIER_D1": "0.5", "RT_HIP_LIGHT_TIER_RATIO": "2", "RT_HIP_GRID_TIER_D1": "0.7"}])
 def test_adversarial_scenes_with_the_grid(oracle, monkeypatch, knobs):
     """The scenes of test_gpu_adversarial.py (a few hundred spheres each: by itself the library would not
