@@ -766,12 +766,14 @@ void build_light_tables(PackedScene &out)
     out.lt_sph.assign(total + RT_LT_PAD, float4{0.f, 0.f, 0.f, -INFINITY});
     out.lt_orig.assign(total + RT_LT_PAD, INT_MAX);
     out.lt_reach.assign(total + RT_LT_PAD, INFINITY);
-    size_t base = 0;
-    for (size_t l = 0; l < jobs; l++) {
+    // Every table's lists lie one behind the other; the tables are filled in side by side.
+    std::vector<size_t> first(jobs + 1, 0);
+    for (size_t l = 0; l < jobs; l++) first[l + 1] = first[l] + per[l].cell.size();
+    auto fill = [&](size_t l) {
         const PerLight &pl = per[l];
         uint2 *cells = out.lt_cells.data() + l * cells_per_light;
         for (uint32_t c : pl.cell) cells[c].y++;
-        size_t off = base;
+        size_t off = first[l];
         for (size_t c = 0; c < cells_per_light; c++) {
             cells[c].x = (uint32_t)off;
             off += cells[c].y;
@@ -784,7 +786,15 @@ void build_light_tables(PackedScene &out)
             out.lt_reach[(size_t)c.x + c.y] = pl.reach[pl.sphere[k]];
             c.y++;
         }
-        base = off;
+    };
+    {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        for (size_t w = 0; w < workers; w++)
+            pool.emplace_back([&] {
+                for (size_t k = next.fetch_add(1); k < jobs; k = next.fetch_add(1)) fill(jobs - 1 - k);
+            });
+        for (std::thread &t : pool) t.join();
     }
     out.lt_n = n;
     out.lt_near = (float)(near * (1.0 - 1e-6));
