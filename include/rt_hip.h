@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RT_API_VERSION 6
+#define RT_API_VERSION 7
 
 /* Primitive type codes — the reference's own flatten uses exactly these
  * (MyApplication.cs:161,166,173). */
@@ -178,8 +178,11 @@ int rt_device_count(void);
  * the image-space partition the reference already uses for its thread pool
  * (Parallel.For over rows, MyApplication.cs:408): device g of G takes the bands g,
  * g + G, ... of 16 rows (contiguous blocks when the frame has fewer than 2 G bands),
- * and every device writes its bands into the first device's frame with one strided
- * copy.
+ * and every device copies its bands into the host's frame itself, over its own PCIe
+ * link, with one strided copy (RT_HIP_HOST_GATHER=0: into the first device's frame over
+ * xGMI, from where one copy brings the frame to the host).
+ * The tuning aids and test knobs of the library (environment variables RT_HIP_*) are read
+ * here, by rt_set_scene and by rt_reload_tuning, never on the way of a frame.
  * Replaces: the Raytracer constructor (MyApplication.cs:392-400).
  */
 int rt_create(rt_ctx **out, const int *device_ids, int n_devices);
@@ -216,9 +219,12 @@ int rt_set_texture(rt_ctx *ctx, int slot, const uint8_t *rgba8, int width, int h
  * literal 5 in `depth < 5` (objects.cs:84); pass RT_REFERENCE_MAX_DEPTH for the
  * reference's behaviour.
  * The copy to pixels_out runs in chunks through page-locked staging memory, the DMA of one
- * chunk overlapping the host-side move of the previous one; on a context with one device and
- * profiling disabled, a frame of 3 M pixels or more is rendered as two to eight row blocks,
- * each copied while the next one renders (same pixels, same rt_get_stats counts).
+ * chunk overlapping the host-side move of the previous one (or straight into pixels_out: rt_pin_pixels,
+ * rt_alloc_pixels); on a context with one device and profiling disabled, a frame of 3 M pixels or more is
+ * rendered as up to eight row blocks whose pipelines overlap (a block starts while the one before it works
+ * through its small deep levels, in a second set of streams and ray queues: twice the device memory
+ * rt_render_rows_device documents for a block), each block copied while the later ones render (same pixels,
+ * same rt_get_stats counts).
  * Replaces: Raytracer.Render() (MyApplication.cs:402-426).
  */
 int rt_render(rt_ctx *ctx, const rt_camera *camera, int width, int height,
@@ -335,7 +341,7 @@ int rt_band_rows(int height, int band_rows, int part, int parts);
  * caller ordered the earlier ones before it, as calls on one context must not overlap) and
  * returns RT_OK, or RT_ERR_STALLED when the device-side schedule of some frame gave up — a
  * workgroup waited longer than the stall limit (one second; environment variable
- * RT_HIP_STALL_MS) for the next level of reflection rays to open — in which case that frame's
+ * RT_HIP_STALL_MS, see rt_reload_tuning) for the next level of reflection rays to open — in which case that frame's
  * pixels are incomplete.  The report is consumed by the call.  rt_render makes the same check
  * itself before it returns.  Costs nothing on the device: a stalled workgroup writes the
  * report into page-locked host memory, nobody else writes anything.
@@ -373,6 +379,10 @@ int rt_debug_rays(rt_ctx *ctx, const rt_camera *camera, int width, int height, i
 /* Counters and timings of the last render call.  Synchronises the context's
  * devices (needed to read the device-side counters). */
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);
+
+/* Reads the library's tuning aids and test knobs (environment variables RT_HIP_*: README, "Tuning aids") again;
+ * rt_create and rt_set_scene do the same.  No frame reads the environment.  No counterpart in the reference. */
+int rt_reload_tuning(rt_ctx *ctx);
 
 /* Profiling mode of later render calls on the context: 0 (default) none; 1 the exact
  * Intersect-call and work counters and event timing (the counting instances of the kernels run:

@@ -133,6 +133,7 @@ EXPORTS = {
     "rt_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "rt_frame_status": (C.c_int, [C.c_void_p]),
     "rt_set_device_share": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_reload_tuning": (C.c_int, [C.c_void_p]),
     "rt_debug_rays": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.POINTER(rt_debug_ray), C.POINTER(C.c_int)]),
     "rt_fxaa_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -165,9 +166,14 @@ def _preload_torch_hip_runtime() -> None:
     the process would hold two HIP/HSA runtimes and the second finds no GPU.  Loading
     torch's copy (when torch is installed; torch itself is not imported) before
     librt_hip.so makes the dynamic loader resolve both to the same runtime.  Hosts
-    without torch (the C# application) simply use the system runtime.
+    without torch (the C# application) simply use the system runtime; RT_HIP_SYSTEM_RUNTIME=1
+    asks for the same in a Python process that does not import torch (the two runtimes differ: the
+    wheel's copies device memory to the host with a shader kernel, the system's with the DMA engines).
     """
     import importlib.util
+    import sys
+    if os.environ.get("RT_HIP_SYSTEM_RUNTIME") and "torch" not in sys.modules:
+        return   # a process that never imports torch (like the C# host): the system's runtime, as librt_hip.so is linked
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):

@@ -136,6 +136,67 @@ struct DeviceState {
     int snap_parts = 0;
 };
 
+
+// Tuning aids and test knobs, all from the environment, read when a context is created, when it gets a
+// scene and by rt_reload_tuning - never on the way of a frame.
+struct Tuning {
+    int chain_policy = -1;       // RT_HIP_CHAIN_POLICY=0/1
+    long long stall_ms = 0;      // RT_HIP_STALL_MS (> 0)
+    int withhold_level = -1;     // RT_HIP_DEBUG_WITHHOLD_LEVEL: the level whose first reflecting tile is never counted
+                                 // as done, which stalls the schedule there on purpose
+    int pipeline = 0;            // RT_HIP_PIPELINE=levels (1) | fused (2)
+    bool level_kernels = false;  // RT_HIP_LEVEL_KERNELS: "levels" on ONE stream (a kernel trace then shows what each launch costs alone)
+    int split_chunks = -1;       // RT_HIP_SPLIT_CHUNKS=0: a tile's chunks stay with its own workgroup
+    int split_below = 0;         // RT_HIP_SPLIT_BELOW=n
+    int spread_below = -1;       // RT_HIP_SPREAD_BELOW=n (0 = never)
+    int light_split_below = -1;  // RT_HIP_LIGHT_SPLIT_BELOW=n (0 = never)
+    int light_waves = 0;         // RT_HIP_LIGHT_WAVES=1..16
+    int bin_min = -1;            // RT_HIP_BIN_MIN=n (0 = never)
+    int early_lights = -1;       // RT_HIP_EARLY_LIGHTS=0 turns the light terms ahead of the children off
+    int early_lights_max = 16;   // RT_HIP_EARLY_LIGHTS_MAX: the most lights it is used for
+    int early_lights_below = -1; // RT_HIP_EARLY_LIGHTS_BELOW: the bound in records (0: every level)
+    int reflect_blocks = 8, plain_blocks = 16, light_blocks = 8;   // RT_HIP_REFLECT_BLOCKS / _PLAIN_BLOCKS / _LIGHT_BLOCKS: workgroups per compute unit
+    size_t copy_chunk_pixels = 0;   // RT_HIP_COPY_CHUNK_KIB
+    int frame_parts = 0;         // RT_HIP_FRAME_PARTS: row blocks of rt_render's frame on one device
+    int part_bands = -1;         // RT_HIP_PART_BANDS=0: contiguous row blocks instead of interleaved bands
+    int host_gather = -1;        // RT_HIP_HOST_GATHER=0: several devices gather on the first one before the copy to the host
+    bool handoff_trace = false;  // RT_HIP_HANDOFF_TRACE (set before the first frame): rt_render prints, per row block, when the
+                                 // host enqueued it and when the device finished its kernels and its copy
+};
+
+Tuning read_tuning()
+{
+    Tuning t;
+    auto num = [](const char *name, long long unset) -> long long {
+        const char *v = getenv(name);
+        return v && *v ? atoll(v) : unset;
+    };
+    t.chain_policy = getenv("RT_HIP_CHAIN_POLICY") ? (num("RT_HIP_CHAIN_POLICY", 0) != 0) : -1;
+    t.stall_ms = std::max(0ll, num("RT_HIP_STALL_MS", 0));
+    t.withhold_level = (int)num("RT_HIP_DEBUG_WITHHOLD_LEVEL", -1);
+    if (const char *v = getenv("RT_HIP_PIPELINE")) t.pipeline = strcmp(v, "fused") == 0 ? 2 : 1;
+    t.level_kernels = getenv("RT_HIP_LEVEL_KERNELS") != nullptr;
+    t.split_chunks = (int)num("RT_HIP_SPLIT_CHUNKS", -1);
+    t.split_below = (int)num("RT_HIP_SPLIT_BELOW", 0);
+    t.spread_below = (int)num("RT_HIP_SPREAD_BELOW", -1);
+    t.light_split_below = (int)num("RT_HIP_LIGHT_SPLIT_BELOW", -1);
+    t.light_waves = (int)num("RT_HIP_LIGHT_WAVES", 0);
+    t.bin_min = (int)num("RT_HIP_BIN_MIN", -1);
+    t.early_lights = (int)num("RT_HIP_EARLY_LIGHTS", -1);
+    t.early_lights_max = (int)num("RT_HIP_EARLY_LIGHTS_MAX", 16);
+    t.early_lights_below = (int)num("RT_HIP_EARLY_LIGHTS_BELOW", -1);
+    auto positive = [&](const char *name, int dflt) { const long long v = num(name, 0); return v > 0 ? (int)v : dflt; };
+    t.reflect_blocks = positive("RT_HIP_REFLECT_BLOCKS", 8);
+    t.plain_blocks = positive("RT_HIP_PLAIN_BLOCKS", 16);
+    t.light_blocks = positive("RT_HIP_LIGHT_BLOCKS", 8);
+    t.copy_chunk_pixels = (size_t)std::max(0ll, num("RT_HIP_COPY_CHUNK_KIB", 0)) * 256;
+    t.frame_parts = (int)num("RT_HIP_FRAME_PARTS", 0);
+    t.part_bands = (int)num("RT_HIP_PART_BANDS", -1);
+    t.host_gather = (int)num("RT_HIP_HOST_GATHER", -1);
+    t.handoff_trace = getenv("RT_HIP_HANDOFF_TRACE") != nullptr;
+    return t;
+}
+
 }  // namespace
 
 // Pixels per chunk of rt_render's staged device-to-host copy (2 MiB: a chunk's DMA takes ~40 us,
@@ -148,6 +209,7 @@ struct rt_ctx {
     bool have_scene = false;
     int profiling = 0;             // RT_PROFILE_*: 0 off, 1 counters and event timing, 2 event timing only
     int share = 1;                 // contexts rendering on this context's devices at the same time (rt_set_device_share)
+    Tuning tune;
     int num_prims = 0, num_lights = 0, ns = 0, np = 0, nt = 0;
     uint32_t textures_used = 0;    // bit i: some primitive names texture slot i
     uint32_t textures_loaded = 0;  // bit i: slot i holds an image
@@ -156,6 +218,7 @@ struct rt_ctx {
     std::vector<hipEvent_t> copy_ev;   // one per chunk of the framebuffer copy to the host (device 0)
     hipStream_t copy_stream = nullptr; // carries those copies while device 0's stream renders the next part
     hipEvent_t part_ev[RT_MAX_FRAME_PARTS] = {};
+    hipEvent_t trace_ev = nullptr;   // RT_HIP_HANDOFF_TRACE: start of the frame on the device
     int32_t *pinned = nullptr;     // the host's own framebuffer, page-locked by rt_pin_pixels
     void *pinned_base = nullptr;   // start of the registered pages
     bool pinned_owned = false;     // the range is page-locked memory of the library's own (rt_alloc_pixels)
@@ -1230,6 +1293,43 @@ hipError_t scratch_address(int device, unsigned char **out)
     return hipSuccess;
 }
 
+
+// Streams, events, the status block and the fixed scratch's address of one device state (the device is current).
+hipError_t create_device_objects(DeviceState &d)
+{
+    hipError_t e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
+    for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipEventCreate(&d.ev[k]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.aux, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming);
+    for (int k = 0; k <= RT_MAX_DEPTH && e == hipSuccess; k++) e = hipEventCreateWithFlags(&d.ev_level[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&d.status, 64, hipHostMallocMapped);
+    if (e == hipSuccess) memset(d.status, 0, 64);
+    if (e == hipSuccess) e = scratch_address(d.device, &d.scratch_base);
+    return e;
+}
+
+// Everything a device state owns.
+void destroy_device_state(DeviceState &d)
+{
+    (void)hipSetDevice(d.device);
+    if (d.stream) (void)hipStreamSynchronize(d.stream);
+    if (d.aux) (void)hipStreamSynchronize(d.aux);
+    free_scene(d);
+    for (int t = 0; t < RT_MAX_TEXTURES; t++)
+        if (d.tex_mem[t]) (void)hipFree(d.tex_mem[t]);
+    if (d.outcome_snap) (void)hipHostFree(d.outcome_snap);
+    free_frame(d);
+    for (int k = 0; k < 5; k++)
+        if (d.ev[k]) (void)hipEventDestroy(d.ev[k]);
+    if (d.ev_fork) (void)hipEventDestroy(d.ev_fork);
+    for (hipEvent_t e : d.ev_level)
+        if (e) (void)hipEventDestroy(e);
+    if (d.aux) (void)hipStreamDestroy(d.aux);
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+    if (d.status) (void)hipHostFree(d.status);
+    if (d.bands) (void)hipFree(d.bands);
+}
+
 // Bytes of the fixed scratch array a frame of P pixels and max_depth + 1 levels needs: the control
 // block, then the three record arrays, each starting on a multiple of 256 bytes.
 size_t fixed_frame_bytes(size_t slots)
@@ -1371,25 +1471,38 @@ int check_schedule(rt_ctx *ctx, DeviceState &d)
 }
 
 // Enqueue the whole frame pipeline for the rows of rs on device state d.
-// part < 0: the call is a frame of its own.  part >= 0: part `part` of a frame rendered in parts —
-// the work counters run on from the earlier parts and the part's outcome is copied to
-// d.outcome_snap behind its kernels.
-// fixed_scratch: the frame's queues live in the library's fixed scratch array and nothing is allocated.
+// call.part < 0: the call is a frame of its own.  call.part >= 0: that part of a frame rendered in parts:
+// its outcome is copied to d.outcome_snap behind its kernels.
+// call.fixed_scratch: the frame's queues live in the library's fixed scratch array and nothing is allocated.
+struct RowsCall {
+    int part = -1;
+    bool keep_counters = false;   // the work counters run on from the parts this device state rendered before
+    bool fixed_scratch = false;
+};
+
 int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h, const RowSet &rs,
-                 int max_depth, int32_t *dev_pixels, hipStream_t stream, int part = -1, bool fixed_scratch = false)
+                 int max_depth, int32_t *dev_pixels, hipStream_t stream, const RowsCall &call = RowsCall())
 {
+    const Tuning &tune = ctx->tune;
+    const int part = call.part;
+    const bool fixed_scratch = call.fixed_scratch;
+
     const long long P64 = (long long)rs.rows * (long long)w;
     if (P64 > INT32_MAX) return fail(ctx, RT_ERR_LIMIT, "row block of %lld pixels exceeds 2^31-1", P64);
     const int P = (int)P64;
-    d.last_P = part > 0 ? d.last_P + P : P;
-    d.last_depth = max_depth;
-    d.snap_parts = part < 0 ? 0 : part + 1;
-    if (P == 0) return RT_OK;   // (a frame rendered in parts has no empty part)
+    if (P == 0) {   // (a frame rendered in parts has no empty part)
+        d.last_P = 0;
+        d.snap_parts = 0;
+        return RT_OK;
+    }
     HIP_TRY(ctx, hipSetDevice(d.device));
     if (part >= 0 && !d.outcome_snap)
         HIP_TRY(ctx, hipHostMalloc((void **)&d.outcome_snap, RT_MAX_FRAME_PARTS * FRAME_OUTCOME_BYTES, hipHostMallocDefault));
     int rc = fixed_scratch ? place_fixed_frame(ctx, d, P, max_depth) : ensure_frame(ctx, d, P, max_depth);
-    if (rc != RT_OK) return rc;
+    if (rc != RT_OK) return rc;   // (nothing enqueued: what rt_get_stats describes stays the previous frame)
+    d.last_P = call.keep_counters ? d.last_P + P : P;
+    d.last_depth = max_depth;
+    d.snap_parts = part < 0 ? 0 : part + 1;
     d.last_fixed = fixed_scratch;
     DevFrame &fr = d.last();
     const DevCamera dc = make_camera(cam, w, h, rs);
@@ -1413,56 +1526,44 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // for its oldest waves first, so a chain tile in a young workgroup crawls while its elders
     // have work.  1/8 of the 4K frame: 0.397 -> 0.362 ms; 1/4 (8 tiles per workgroup): 0.547 ->
     // 0.571, hence the bound.  RT_HIP_CHAIN_POLICY=0/1 (tuning aid) overrides.
-    static const char *policy_env = getenv("RT_HIP_CHAIN_POLICY");
-    fr.chain_policy = policy_env ? (atoi(policy_env) != 0)
-                                      : tiles0 < RT_CHAIN_RESERVED_TILES_PER_WORKGROUP * resident_plain;
+    fr.chain_policy = tune.chain_policy >= 0 ? tune.chain_policy
+                                             : tiles0 < RT_CHAIN_RESERVED_TILES_PER_WORKGROUP * resident_plain;
     fr.num_cus = d.num_cus;
     // ... and for the instance this frame launches (workgroups beyond what is resident at once
     // would only start when the first ones leave, find nothing to claim and exit).
     const int resident_blocks = std::max(d.num_cus / 2, resident(fr.chain_policy != 0) / share);
     fr.status = d.status;
-    const char *stall_env = getenv("RT_HIP_STALL_MS");   // (read at every call, like the knob below)
-    const long long stall_ms = stall_env && atoll(stall_env) > 0 ? atoll(stall_env) : (long long)RT_STALL_MS_DEFAULT;
+    const long long stall_ms = tune.stall_ms > 0 ? tune.stall_ms : (long long)RT_STALL_MS_DEFAULT;
     fr.stall_ticks = (unsigned)std::min<long long>(stall_ms * 100000ll, 4000000000ll);   // 100 MHz wall clock
-    // RT_HIP_DEBUG_WITHHOLD_LEVEL (test knob, read at every call): the level whose first reflecting
-    // tile is never counted as done, which stalls the schedule there on purpose.
-    const char *withhold_env = getenv("RT_HIP_DEBUG_WITHHOLD_LEVEL");
-    fr.debug_withhold = withhold_env ? atoi(withhold_env) : -1;
-    const char *pipeline_env = getenv("RT_HIP_PIPELINE");   // (read at every call; see below)
+    fr.debug_withhold = tune.withhold_level;
     const bool grid = d.scene.gr_n[0] > 0;   // reflection rays walk the spheres' grid (k_reflect_grid): no chunks, no LDS
-    static const bool level_kernels = getenv("RT_HIP_LEVEL_KERNELS") != nullptr;
+    const bool level_kernels = tune.level_kernels;
     // (the fused form pays only where several small frames are in flight on the device at once - there its
     // single launch per frame beats the levels' chains of short launches, 1/8 of the 4K frame with four in
     // flight: 0.106 against 0.127 ms - and the scene is one chunk; a frame alone on the device: 0.33 against
     // 0.20 ms, 256x256 of the 64k-sphere scene: 9.1 against 1.5 ms)
-    const bool fused = pipeline_env ? strcmp(pipeline_env, "fused") == 0
-                                    : !level_kernels && share >= 4 && (d.scene.ns_padded <= RT_CHUNK || grid) &&
+    const bool fused = tune.pipeline ? tune.pipeline == 2
+                                     : !level_kernels && share >= 4 && (d.scene.ns_padded <= RT_CHUNK || grid) &&
                                           tiles0 < RT_FUSED_BELOW_TILES_PER_WORKGROUP * resident(false);
     // Scenes of several chunks, one launch per level: the reflection rays of a level are traced as
     // (tile, chunk) jobs (k_reflect_chunks).  RT_HIP_SPLIT_CHUNKS=0 (tuning aid) keeps a tile's chunks
     // to its own workgroup.
-    const char *split_chunks_env = getenv("RT_HIP_SPLIT_CHUNKS"), *split_below_str = getenv("RT_HIP_SPLIT_BELOW");
-    const bool split_env = !split_chunks_env || atoi(split_chunks_env) != 0;
-    fr.split_chunks = !fused && !grid && split_env && d.scene.ns_padded > RT_CHUNK ? 1 : 0;
-    const int split_below_env = split_below_str ? atoi(split_below_str) : 0;
-    fr.split_below = split_below_env > 0 ? split_below_env : std::max(1, d.num_cus * 2 / share);
+    fr.split_chunks = !fused && !grid && tune.split_chunks != 0 && d.scene.ns_padded > RT_CHUNK ? 1 : 0;
+    fr.split_below = tune.split_below > 0 ? tune.split_below : std::max(1, d.num_cus * 2 / share);
     // Scenes of one chunk, one launch per level: a level with fewer reflecting tiles than this is traced 64
     // records per workgroup, the scene spread over the workgroup's waves.  RT_HIP_SPREAD_BELOW=n (tuning
     // aid; 0 = never).
-    const char *spread_below_str = getenv("RT_HIP_SPREAD_BELOW");
     // (on a large frame the plain records' launches keep the device busy beside the chain, and the four times as
     // many workgroups of the spread form only take from them: 3840x2160 0.552 ms with a bound of 128 tiles
     // against 0.562 with 512, 1920x1080 0.259 against 0.250)
-    fr.spread_below = fused || grid ? 0 : spread_below_str ? atoi(spread_below_str)
+    fr.spread_below = fused || grid ? 0 : tune.spread_below >= 0 ? tune.spread_below
                                           : std::max(1, (tiles0 >= 16384 ? d.num_cus / 2 : d.num_cus * 2) / share);
     // Scenes with several lights, one launch per level: short queues are shaded with the lights spread
     // over the waves of a workgroup (k_shade_lights).  RT_HIP_LIGHT_SPLIT_BELOW=n (tuning aid; 0 = never).
-    const char *light_below_str = getenv("RT_HIP_LIGHT_SPLIT_BELOW");   // (these knobs are read at every call)
-    const int light_below_env = light_below_str ? atoi(light_below_str) : -1;
+    const int light_below_env = tune.light_split_below;
     const int nl = d.scene.nl;
     fr.light_waves = fused || nl < 3 || light_below_env == 0 ? 0 : nl >= 12 ? 16 : nl >= 6 ? 8 : 4;
-    if (const char *e = getenv("RT_HIP_LIGHT_WAVES"))   // tuning aid: waves per workgroup of k_shade_lights
-        if (fr.light_waves && atoi(e) >= 1 && atoi(e) <= 16) fr.light_waves = atoi(e);
+    if (fr.light_waves && tune.light_waves >= 1 && tune.light_waves <= 16) fr.light_waves = tune.light_waves;   // RT_HIP_LIGHT_WAVES
     // (The more lights, the longer the queues it pays for: a wave of k_shade_lights looks one light up for 64
     // neighbouring records - one table, nearby cells - where a lane of k_plain goes through all the tables.
     // 16 lights: 4.04 ms per frame with queues below 64 K records, 3.88 below 256 K, 3.64 below 512 K or 1 M, 4.3 for all.)
@@ -1470,8 +1571,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // Scenes of several chunks or many lights, one launch per level: the records of a level >= 1 are put
     // into the order of their hit points' position bins before the level is used (k_bin_*).
     // RT_HIP_BIN_MIN=n (tuning aid): for levels of at least n records; 0 = never.
-    const char *bin_min_str = getenv("RT_HIP_BIN_MIN");
-    const int bin_min_env = bin_min_str ? atoi(bin_min_str) : -1;
+    const int bin_min_env = tune.bin_min;
     fr.bin_min = 0;
     fr.stage_base = 0;
     fr.staged = 0;
@@ -1514,7 +1614,6 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // light; not beyond RT_LIT_MAX_BYTES.  RT_HIP_EARLY_LIGHTS=0 (tuning aid) turns it off.
     fr.lit = nullptr;
     {
-        const char *early_env = getenv("RT_HIP_EARLY_LIGHTS");
         // (not for a context that shares its device with others rendering at the same time: there the
         // tail of one frame is filled by the other frames' kernels anyway, and the extra traffic costs 5 %)
         // With more than four lights only for the levels of few reflecting records: their passes at the end of
@@ -1522,14 +1621,13 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
         // costs its work wherever it runs (the 16 lights of the 64k-sphere scene with every level ahead: the
         // frame's tail shrinks by 1.2 ms and the stage grows by as much).  RT_HIP_EARLY_LIGHTS_MAX: the most
         // lights it is used for; RT_HIP_EARLY_LIGHTS_BELOW: the bound in records (0: every level); tuning aids.
-        const char *lit_lights_env = getenv("RT_HIP_EARLY_LIGHTS_MAX"), *lit_below_env = getenv("RT_HIP_EARLY_LIGHTS_BELOW");
-        const int lit_lights = lit_lights_env ? atoi(lit_lights_env) : 16;
-        fr.lit_below = nl <= 4 ? 0 : lit_below_env ? atoi(lit_below_env) : 65536;
+        const int lit_lights = tune.early_lights_max;
+        fr.lit_below = nl <= 4 ? 0 : tune.early_lights_below >= 0 ? tune.early_lights_below : 65536;
         // (a level with its terms ahead holds fewer than lit_below reflecting records)
         fr.lit_stride = fr.lit_below > 0 ? std::min(fr.P, fr.lit_below) : fr.P;
         const size_t want = (size_t)fr.lit_stride * (size_t)max_depth * (size_t)std::max(nl, 1);
         if (!fused && !fixed_scratch && share == 1 && max_depth > 0 && nl >= 1 && nl <= lit_lights &&
-            (!early_env || atoi(early_env) != 0) &&
+            tune.early_lights != 0 &&
             want * sizeof(float4) <= RT_LIT_MAX_BYTES) {
             if (want > d.cap_lit && want < d.lit_refused) {
                 if (d.lit) (void)hipFree(d.lit);
@@ -1548,17 +1646,13 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     }
     d.last_stream = stream;
     const DevFrame &f = fr;
-    if (part > 0) HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, FRAME_CONTROL_BYTES - RT_COUNTER_SLOTS * sizeof(DevCounters), stream));
+    if (call.keep_counters) HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, FRAME_CONTROL_BYTES - RT_COUNTER_SLOTS * sizeof(DevCounters), stream));
     else HIP_TRY(ctx, hipMemsetAsync(f.counters, 0, FRAME_CONTROL_BYTES, stream));
     d.timed = ctx->profiling != 0;
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
     // Workgroups per compute unit of the per-level launches (RT_HIP_REFLECT_BLOCKS / RT_HIP_PLAIN_BLOCKS /
     // RT_HIP_LIGHT_BLOCKS, tuning aids, override the defaults).
-    auto per_cu = [](const char *name, int dflt) {
-        const char *v = getenv(name);
-        return v && atoi(v) > 0 ? atoi(v) : dflt;
-    };
-    const int blocks = std::max(1, std::min({(P + 255) / 256, d.num_cus * per_cu("RT_HIP_REFLECT_BLOCKS", 8) / std::max(1, ctx->share),
+    const int blocks = std::max(1, std::min({(P + 255) / 256, d.num_cus * tune.reflect_blocks / std::max(1, ctx->share),
                                              RT_COUNTER_SLOTS}));
     // k_primary's workgroups claim their 32x32-pixel tiles dynamically: as many workgroups as are
     // resident at once (4 per compute unit) when each gets several tiles, twice that on small frames
@@ -1579,8 +1673,8 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     if (!fused) {
         // (counting kernels add to per-workgroup counter slots without atomics: one stream then)
         const bool two_streams = !level_kernels && !counting && max_depth > 0;
-        const int plain_blocks = std::max(1, std::min({tiles0, d.num_cus * per_cu("RT_HIP_PLAIN_BLOCKS", 16) / share, RT_COUNTER_SLOTS}));
-        const int light_blocks = std::max(1, std::min(d.num_cus * per_cu("RT_HIP_LIGHT_BLOCKS", 8) / share, RT_COUNTER_SLOTS));
+        const int plain_blocks = std::max(1, std::min({tiles0, d.num_cus * tune.plain_blocks / share, RT_COUNTER_SLOTS}));
+        const int light_blocks = std::max(1, std::min(d.num_cus * tune.light_blocks / share, RT_COUNTER_SLOTS));
         // The chain stays on the caller's stream (a dependency between two launches of one stream costs
         // ~6 us, across streams ~12, and the chain is the frame's critical path); the plain records'
         // launches go to the second stream, except the deepest level's, which the chain ends with.
@@ -1670,6 +1764,7 @@ int rt_create(rt_ctx **out, const int *device_ids, int n_devices)
             return fail(nullptr, RT_ERR_NO_DEVICE, "device id %d outside [0, %d)", id, count);
     rt_ctx *ctx = new (std::nothrow) rt_ctx();
     if (!ctx) return fail(nullptr, RT_ERR_OUT_OF_MEMORY, "out of host memory");
+    ctx->tune = read_tuning();
     ctx->dev.resize(ids.size());
     for (size_t i = 0; i < ids.size(); i++) {
         DeviceState &d = ctx->dev[i];
@@ -1683,14 +1778,7 @@ int rt_create(rt_ctx **out, const int *device_ids, int n_devices)
             rt_destroy(ctx);
             return rc;
         }
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
-        for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipEventCreate(&d.ev[k]);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.aux, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming);
-        for (int k = 0; k <= RT_MAX_DEPTH && e == hipSuccess; k++) e = hipEventCreateWithFlags(&d.ev_level[k], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipHostMalloc((void **)&d.status, 64, hipHostMallocMapped);
-        if (e == hipSuccess) memset(d.status, 0, 64);
-        if (e == hipSuccess) e = scratch_address(d.device, &d.scratch_base);
+        if (e == hipSuccess) e = create_device_objects(d);
         if (e != hipSuccess) {
             int rc = fail(nullptr, RT_ERR_HIP, "device %d setup failed: %s", d.device, hipGetErrorString(e));
             rt_destroy(ctx);
@@ -1726,30 +1814,13 @@ int rt_create(rt_ctx **out, const int *device_ids, int n_devices)
 void rt_destroy(rt_ctx *ctx)
 {
     if (!ctx) return;
-    for (DeviceState &d : ctx->dev) {
-        (void)hipSetDevice(d.device);
-        if (d.stream) (void)hipStreamSynchronize(d.stream);
-        free_scene(d);
-        for (int t = 0; t < RT_MAX_TEXTURES; t++)
-            if (d.tex_mem[t]) (void)hipFree(d.tex_mem[t]);
-        free_frame(d);
-        for (int k = 0; k < 5; k++)
-            if (d.ev[k]) (void)hipEventDestroy(d.ev[k]);
-        if (d.aux) (void)hipStreamSynchronize(d.aux);
-        if (d.ev_fork) (void)hipEventDestroy(d.ev_fork);
-        for (hipEvent_t e : d.ev_level)
-            if (e) (void)hipEventDestroy(e);
-        if (d.aux) (void)hipStreamDestroy(d.aux);
-        if (d.stream) (void)hipStreamDestroy(d.stream);
-        if (d.outcome_snap) (void)hipHostFree(d.outcome_snap);
-        if (d.status) (void)hipHostFree(d.status);
-        if (d.bands) (void)hipFree(d.bands);
-    }
+    for (DeviceState &d : ctx->dev) destroy_device_state(d);
     if (ctx->staging) (void)hipHostFree(ctx->staging);
     if (!ctx->dev.empty()) (void)hipSetDevice(ctx->dev[0].device);
     for (hipEvent_t e : ctx->copy_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->part_ev)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->trace_ev) (void)hipEventDestroy(ctx->trace_ev);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->pinned) (void)(ctx->pinned_owned ? hipHostFree(ctx->pinned_base) : hipHostUnregister(ctx->pinned_base));
     delete ctx;
@@ -1765,6 +1836,13 @@ int rt_set_profiling(rt_ctx *ctx, int enable)
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (enable < 0 || enable > 2) return fail(ctx, RT_ERR_INVALID_ARG, "profiling mode %d is none of 0, 1, 2", enable);
     ctx->profiling = enable;
+    return RT_OK;
+}
+
+int rt_reload_tuning(rt_ctx *ctx)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    ctx->tune = read_tuning();
     return RT_OK;
 }
 
@@ -1790,6 +1868,7 @@ int rt_set_scene(rt_ctx *ctx, const rt_scene *s)
     if (s->num_lights > 0 && (!s->light_positions || !s->light_colors))
         return fail(ctx, RT_ERR_INVALID_ARG, "a light array is NULL");
     return guarded(ctx, [&]() -> int {
+    ctx->tune = read_tuning();
     PackedScene ps;
     int rc = pack_scene(ctx, s, ps);
     if (rc != RT_OK) return rc;
@@ -1869,8 +1948,10 @@ int rt_render_rows_device_noalloc(rt_ctx *ctx, const rt_camera *cam, int w, int 
     ctx->last_h = h;
     ctx->copy_ms = ctx->gather_ms = 0.0;
     for (size_t i = 1; i < ctx->dev.size(); i++) ctx->dev[i].last_P = 0;
+    RowsCall fixed;
+    fixed.fixed_scratch = true;
     return enqueue_rows(ctx, d, cam, w, h, contiguous_rows(row_begin, row_end), max_depth, dev_pixels_out,
-                        hip_stream ? static_cast<hipStream_t>(hip_stream) : d.stream, -1, true);
+                        hip_stream ? static_cast<hipStream_t>(hip_stream) : d.stream, fixed);
     });
 }
 
@@ -1904,12 +1985,14 @@ int rt_render_bands_device(rt_ctx *ctx, const rt_camera *cam, int w, int h, int 
 static int render_to_host(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth, int32_t *pixels_out)
 {
     int rc = RT_OK;
+    const Tuning &tune = ctx->tune;
     const long long total = (long long)w * (long long)h;
     if (total > INT32_MAX) return fail(ctx, RT_ERR_LIMIT, "frame of %lld pixels exceeds 2^31-1", total);
     const int G = (int)ctx->dev.size();
     ctx->last_was_rows_device = false;
     ctx->last_w = w;
     ctx->last_h = h;
+    const auto t_call = std::chrono::steady_clock::now();
 
     // Contiguous row blocks, one per device (rows like the outer Parallel.For).
     ctx->last_rows.assign(G + 1, 0);
@@ -1917,99 +2000,171 @@ static int render_to_host(rt_ctx *ctx, const rt_camera *cam, int w, int h, int m
 
     DeviceState &root = ctx->dev[0];
     HIP_TRY(ctx, hipSetDevice(root.device));
-    if ((size_t)total > root.cap_out) {
+    bool all_peers = true;
+    for (const DeviceState &d : ctx->dev) all_peers = all_peers && d.peer_to_root;
+    // Several devices: every device copies its own rows to the host over its own PCIe link (RT_HIP_HOST_GATHER=0,
+    // tuning aid: they first meet in the first device's memory, over xGMI, and one copy brings the frame to the host).
+    const bool host_gather = G > 1 && tune.host_gather != 0;
+    if (!host_gather && (size_t)total > root.cap_out) {
         if (root.out) (void)hipFree(root.out);
         root.out = nullptr;
         root.cap_out = 0;
         HIP_TRY(ctx, hipMalloc((void **)&root.out, (size_t)total * sizeof(int32_t)));
         root.cap_out = (size_t)total;
     }
+    // The copy to the host goes straight into the caller's array when it is page-locked (rt_pin_pixels,
+    // rt_alloc_pixels), else into page-locked staging memory and from there into the caller's (pageable) array.
     const bool direct = ctx->pinned && pixels_out >= ctx->pinned &&
                         (size_t)(pixels_out - ctx->pinned) + (size_t)total <= ctx->pinned_count;
-    bool all_peers = true;
-    for (const DeviceState &d : ctx->dev) all_peers = all_peers && d.peer_to_root;
-    if ((!direct || !all_peers) && (size_t)total > ctx->cap_staging) {
+    if ((!direct || (!host_gather && !all_peers)) && (size_t)total > ctx->cap_staging) {
         if (ctx->staging) (void)hipHostFree(ctx->staging);
         ctx->staging = nullptr;
         ctx->cap_staging = 0;
         HIP_TRY(ctx, hipHostMalloc((void **)&ctx->staging, (size_t)total * sizeof(int32_t), hipHostMallocDefault));
         ctx->cap_staging = (size_t)total;
     }
-    // The copy to the host: straight into the caller's array when it is page-locked
-    // (rt_pin_pixels), else into pinned staging and from there into the caller's (pageable)
-    // array.  It goes in chunks: while the DMA engine brings chunk k+1 the caller's thread moves
-    // chunk k on into the array, so the frame costs the slower of the two transfers, not their sum.
-    struct Chunk {
-        size_t off, len;
+    int32_t *const host = direct ? pixels_out : ctx->staging;
+    // A piece of the frame on its way to the host: `runs` runs of `len` pixels, `stride` pixels apart, the first at
+    // pixel `off`; ctx->copy_ev[k] of piece k says that it has arrived.  A staged frame goes in pieces of ~2 MiB:
+    // while the DMA engine brings piece k + 1 the caller's thread moves piece k on into the array, so the frame
+    // costs the slower of the two transfers, not their sum.  A direct one needs no pieces smaller than what
+    // finishes together.
+    struct Piece {
+        size_t off, len, stride, runs;
     };
-    std::vector<Chunk> chunks;
-    // RT_HIP_COPY_CHUNK_KIB (tuning aid): chunk size in KiB.
-    static const char *chunk_env = getenv("RT_HIP_COPY_CHUNK_KIB");
-    const size_t chunk = chunk_env && atoll(chunk_env) > 0 ? (size_t)atoll(chunk_env) * 256 : RT_STAGED_COPY_CHUNK_PIXELS;
-    // Enqueues the copy of pixels [off, off + count) on `stream`, one event per chunk.
-    auto enqueue_copy = [&](size_t off, size_t count, hipStream_t stream) -> int {
+    std::vector<Piece> pieces;
+    const size_t chunk = direct ? (size_t)total : tune.copy_chunk_pixels ? tune.copy_chunk_pixels : RT_STAGED_COPY_CHUNK_PIXELS;
+    auto piece_event = [&](hipStream_t stream, const Piece &pc) -> int {
+        if (ctx->copy_ev.size() <= pieces.size()) {
+            hipEvent_t e;
+            HIP_TRY(ctx, hipEventCreateWithFlags(&e, tune.handoff_trace ? hipEventDefault : hipEventDisableTiming));
+            ctx->copy_ev.push_back(e);
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->copy_ev[pieces.size()], stream));
+        pieces.push_back(pc);
+        return RT_OK;
+    };
+    // Enqueues the copy of the frame's pixels [off, off + count) from src (which holds them in frame order).
+    auto enqueue_copy = [&](const int32_t *src, size_t off, size_t count, hipStream_t stream) -> int {
         for (size_t o = off; o < off + count; o += chunk) {
             const size_t len = std::min(chunk, off + count - o);
-            if (ctx->copy_ev.size() <= chunks.size()) {
-                hipEvent_t e;
-                HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                ctx->copy_ev.push_back(e);
-            }
-            HIP_TRY(ctx, hipMemcpyAsync((direct ? pixels_out : ctx->staging) + o, root.out + o, len * sizeof(int32_t),
-                                        hipMemcpyDeviceToHost, stream));
-            HIP_TRY(ctx, hipEventRecord(ctx->copy_ev[chunks.size()], stream));
-            chunks.push_back(Chunk{o, len});
+            HIP_TRY(ctx, hipMemcpyAsync(host + o, src + (o - off), len * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            int r = piece_event(stream, Piece{o, len, len, 1});
+            if (r != RT_OK) return r;
         }
         return RT_OK;
     };
-    // Waits for the chunks in order and, when staged, moves each on into the caller's array.
+    // Waits for the pieces in order and, when staged, moves each on into the caller's array.
     auto drain_copy = [&]() -> int {
-        for (size_t k = 0; k < chunks.size(); k++) {
+        for (size_t k = 0; k < pieces.size(); k++) {
             HIP_TRY(ctx, hipEventSynchronize(ctx->copy_ev[k]));
-            if (!direct) copy_streaming(pixels_out + chunks[k].off, ctx->staging + chunks[k].off, chunks[k].len * sizeof(int32_t));
+            if (!direct)
+                for (size_t r = 0; r < pieces[k].runs; r++)
+                    copy_streaming(pixels_out + pieces[k].off + r * pieces[k].stride, ctx->staging + pieces[k].off + r * pieces[k].stride,
+                                   pieces[k].len * sizeof(int32_t));
         }
         if (!direct) store_fence();   // the streaming stores are visible before the call returns
         return RT_OK;
     };
 
-    // One device, a large frame, nobody timing the kernels: render the frame as row blocks one
-    // after the other and copy each finished block while the next one renders.
-    // RT_HIP_FRAME_PARTS (tuning aid): number of blocks.
+    // One device, a large frame, nobody timing the kernels: the frame is rendered as row blocks one after the
+    // other and each finished block is copied while the next one renders.  A block is every parts-th band of
+    // RT_BAND_ROWS rows (rows cost very different amounts - the reflecting ceiling fills the top of the reference's
+    // view - and with contiguous halves the 3840x2160 frame's first block took 0.45 ms and its second 0.31; a frame
+    // costs its blocks' kernels plus the last block's copy), rendered stacked into its part of the device frame and
+    // put in place by ONE strided copy to the host (source pitch = a band, destination pitch = parts bands).
+    // Blocks in flight side by side, each in streams and ray queues of its own, were tried and are gone: kernels of
+    // different hardware queues take the device from one another (two halves 1.35 ms against 1.07 one after the
+    // other; the frame is bound by the work it issues, not by idle stretches another block could fill).
+    // RT_HIP_FRAME_PARTS / RT_HIP_PART_BANDS=0 (tuning aids): number of blocks, contiguous blocks.
     int parts = 1;
     if (G == 1 && !ctx->profiling) {
-        static const char *parts_env = getenv("RT_HIP_FRAME_PARTS");
-        parts = parts_env ? atoi(parts_env)
-                          : total < RT_MIN_SPLIT_PIXELS ? 1 : std::max(2, (int)(total / RT_PART_PIXELS));
+        parts = tune.frame_parts > 0 ? tune.frame_parts
+                                      : total < RT_MIN_SPLIT_PIXELS ? 1 : std::max(2, (int)(total / RT_PART_PIXELS));
         parts = std::max(1, std::min({parts, RT_MAX_FRAME_PARTS, h}));
     }
     if (parts > 1) {
+        const bool bands = tune.part_bands != 0 && h >= 2 * parts * RT_BAND_ROWS;
+        const size_t band_px = (size_t)RT_BAND_ROWS * (size_t)w;
+        const int nbands = (h + RT_BAND_ROWS - 1) / RT_BAND_ROWS;
         if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-        const auto t0 = std::chrono::steady_clock::now();
+        double host_t[RT_MAX_FRAME_PARTS][2] = {};
+        size_t first_piece[RT_MAX_FRAME_PARTS + 1] = {};
+        size_t done_px = 0;   // pixels of the blocks enqueued so far = where the next block lies in root.out
         for (int p = 0; p < parts; p++) {
+            if (!ctx->part_ev[p])
+                HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->part_ev[p], tune.handoff_trace ? hipEventDefault : hipEventDisableTiming));
+            if (p == 0 && tune.handoff_trace) {
+                if (!ctx->trace_ev) HIP_TRY(ctx, hipEventCreate(&ctx->trace_ev));
+                HIP_TRY(ctx, hipEventRecord(ctx->trace_ev, root.stream));
+            }
+            host_t[p][0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
             const int y0 = (int)(((long long)h * p) / parts), y1 = (int)(((long long)h * (p + 1)) / parts);
-            const size_t off = (size_t)y0 * (size_t)w;
-            if ((rc = enqueue_rows(ctx, root, cam, w, h, contiguous_rows(y0, y1), max_depth, root.out + off, root.stream, p)) != RT_OK)
-                return rc;
-            if (!ctx->part_ev[p]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->part_ev[p], hipEventDisableTiming));
+            const RowSet rs = bands ? RowSet{0, rows_of_part(h, RT_BAND_ROWS, p, parts), RT_BAND_ROWS, parts, p} : contiguous_rows(y0, y1);
+            const size_t block = (size_t)rs.rows * (size_t)w;
+            int32_t *const src = root.out + done_px;
+            RowsCall call;
+            call.part = p;
+            call.keep_counters = p > 0;
+            if ((rc = enqueue_rows(ctx, root, cam, w, h, rs, max_depth, src, root.stream, call)) != RT_OK) return rc;
             HIP_TRY(ctx, hipEventRecord(ctx->part_ev[p], root.stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->part_ev[p], 0));
-            if ((rc = enqueue_copy(off, (size_t)(y1 - y0) * (size_t)w, ctx->copy_stream)) != RT_OK) return rc;
+            if (!bands) {
+                if ((rc = enqueue_copy(src, (size_t)y0 * (size_t)w, block, ctx->copy_stream)) != RT_OK) return rc;
+            } else {
+                const int mine = (nbands - p + parts - 1) / parts;                // bands of block p
+                const bool short_last = h % RT_BAND_ROWS != 0 && (nbands - 1) % parts == p;
+                const int full = short_last ? mine - 1 : mine;                     // of full height
+                // (a staged frame's bands go in several strided copies, so that the caller's thread moves the first
+                // ones on while the later ones travel)
+                const int step = direct ? std::max(1, full) : std::max(1, (int)(chunk / band_px));
+                for (int b = 0; b < full; b += step) {
+                    const int n = std::min(step, full - b);
+                    const size_t first = ((size_t)b * (size_t)parts + (size_t)p) * band_px;   // the frame's pixel the copy starts at
+                    HIP_TRY(ctx, hipMemcpy2DAsync(host + first, (size_t)parts * band_px * sizeof(int32_t), src + (size_t)b * band_px,
+                                                  band_px * sizeof(int32_t), band_px * sizeof(int32_t), (size_t)n,
+                                                  hipMemcpyDeviceToHost, ctx->copy_stream));
+                    if ((rc = piece_event(ctx->copy_stream, Piece{first, band_px, (size_t)parts * band_px, (size_t)n})) != RT_OK) return rc;
+                }
+                if (short_last) {
+                    const size_t first = (size_t)(nbands - 1) * band_px, len = (size_t)(h - (nbands - 1) * RT_BAND_ROWS) * (size_t)w;
+                    HIP_TRY(ctx, hipMemcpyAsync(host + first, src + (size_t)full * band_px, len * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                                ctx->copy_stream));
+                    if ((rc = piece_event(ctx->copy_stream, Piece{first, len, len, 1})) != RT_OK) return rc;
+                }
+            }
+            done_px += block;
+            host_t[p][1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
+            first_piece[p + 1] = pieces.size();
         }
         if ((rc = drain_copy()) != RT_OK) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(root.stream));   // (done already: the copies waited for the kernels)
         ctx->gather_ms = 0.0;
         // Here the copy overlaps the kernels: what is reported is the time of the whole call.
-        ctx->copy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        ctx->copy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+        if (tune.handoff_trace) {
+            fprintf(stderr, "[rt_hip] rt_render %dx%d, %d %s blocks: %.1f us\n", w, h, parts, bands ? "interleaved" : "contiguous",
+                    ctx->copy_ms * 1e3);
+            for (int p = 0; p < parts; p++) {
+                float k = -1.f, c = -1.f;
+                (void)hipEventElapsedTime(&k, ctx->trace_ev, ctx->part_ev[p]);
+                (void)hipEventElapsedTime(&c, ctx->trace_ev, ctx->copy_ev[first_piece[p + 1] - 1]);
+                fprintf(stderr, "[rt_hip]   block %d: host enqueue %.1f .. %.1f us; device: kernels done %.1f us, copy done %.1f us\n", p,
+                        host_t[p][0], host_t[p][1], k * 1e3, c * 1e3);
+            }
+            (void)hipGetLastError();
+        }
         return check_schedule(ctx, root);
     }
 
     // Several devices and enough rows: device g takes the bands g, g + G, ... of RT_BAND_ROWS rows
     // (rows cost very different amounts; interleaved, every device gets its share of the
-    // expensive ones), renders them stacked into a block of its own and writes them into device
-    // 0's frame with ONE strided copy: source pitch = a band, destination pitch = G bands.
-    // (A device that cannot write device 0's memory takes a contiguous block, which it can hand
+    // expensive ones) and renders them stacked into a block of its own.  ONE strided copy per device
+    // (source pitch = a band, destination pitch = G bands) then puts them where they belong: in the host's frame,
+    // every device over its own PCIe link at the same time, or (RT_HIP_HOST_GATHER=0) in device 0's frame over xGMI.
+    // (Device gather: a device that cannot write device 0's memory takes a contiguous block, which it can hand
     // over through host memory in one piece.)
-    const bool interleaved = G > 1 && h >= 2 * G * RT_BAND_ROWS && all_peers;
+    const bool interleaved = G > 1 && h >= 2 * G * RT_BAND_ROWS && (host_gather || all_peers);
     if (interleaved) {
         const size_t band_px = (size_t)RT_BAND_ROWS * (size_t)w;
         const int nbands = (h + RT_BAND_ROWS - 1) / RT_BAND_ROWS;
@@ -2027,20 +2182,29 @@ static int render_to_host(rt_ctx *ctx, const rt_camera *cam, int w, int h, int m
             }
             if ((rc = enqueue_rows(ctx, d, cam, w, h, rs, max_depth, d.bands, d.stream)) != RT_OK) return rc;
         }
+        // A staged frame's bands go in several strided copies per device, so that the caller's thread can move the
+        // first ones on while the later ones travel.
         for (int g = 0; g < G; g++) {
             DeviceState &d = ctx->dev[g];
             const int mine = (nbands - g + G - 1) / G;                      // bands of device g
             const bool short_last = h % RT_BAND_ROWS != 0 && (nbands - 1) % G == g;
             const int full = short_last ? mine - 1 : mine;                  // of full height
+            int32_t *const target = host_gather ? host : root.out;
+            const hipMemcpyKind kind = host_gather ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
             HIP_TRY(ctx, hipSetDevice(d.device));
-            if (full > 0)
-                HIP_TRY(ctx, hipMemcpy2DAsync(root.out + (size_t)g * band_px, (size_t)G * band_px * sizeof(int32_t), d.bands,
-                                              band_px * sizeof(int32_t), band_px * sizeof(int32_t), (size_t)full,
-                                              hipMemcpyDeviceToDevice, d.stream));
-            if (short_last)
-                HIP_TRY(ctx, hipMemcpyAsync(root.out + (size_t)(nbands - 1) * band_px, d.bands + (size_t)full * band_px,
-                                            (size_t)(h - (nbands - 1) * RT_BAND_ROWS) * (size_t)w * sizeof(int32_t),
-                                            hipMemcpyDeviceToDevice, d.stream));
+            const int step = host_gather && !direct ? std::max(1, (int)(chunk / band_px)) : std::max(1, full);
+            for (int b = 0; b < full; b += step) {
+                const int n = std::min(step, full - b);
+                const size_t first = ((size_t)b * (size_t)G + (size_t)g) * band_px;   // the frame's pixel the copy starts at
+                HIP_TRY(ctx, hipMemcpy2DAsync(target + first, (size_t)G * band_px * sizeof(int32_t), d.bands + (size_t)b * band_px,
+                                              band_px * sizeof(int32_t), band_px * sizeof(int32_t), (size_t)n, kind, d.stream));
+                if (host_gather && (rc = piece_event(d.stream, Piece{first, band_px, (size_t)G * band_px, (size_t)n})) != RT_OK) return rc;
+            }
+            if (short_last) {
+                const size_t first = (size_t)(nbands - 1) * band_px, len = (size_t)(h - (nbands - 1) * RT_BAND_ROWS) * (size_t)w;
+                HIP_TRY(ctx, hipMemcpyAsync(target + first, d.bands + (size_t)full * band_px, len * sizeof(int32_t), kind, d.stream));
+                if (host_gather && (rc = piece_event(d.stream, Piece{first, len, len, 1})) != RT_OK) return rc;
+            }
             if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[4], d.stream));
         }
     } else {
@@ -2049,8 +2213,8 @@ static int render_to_host(rt_ctx *ctx, const rt_camera *cam, int w, int h, int m
             DeviceState &d = ctx->dev[g];
             const int y0 = ctx->last_rows[g], y1 = ctx->last_rows[g + 1];
             const size_t block = (size_t)(y1 - y0) * (size_t)w;
-            int32_t *target = root.out + (size_t)y0 * (size_t)w;
-            if (g > 0) {
+            int32_t *target = host_gather ? nullptr : root.out + (size_t)y0 * (size_t)w;
+            if (g > 0 || host_gather) {
                 HIP_TRY(ctx, hipSetDevice(d.device));
                 if (block > d.cap_out) {
                     if (d.out) (void)hipFree(d.out);
@@ -2062,10 +2226,14 @@ static int render_to_host(rt_ctx *ctx, const rt_camera *cam, int w, int h, int m
                 target = d.out;
             }
             if ((rc = enqueue_rows(ctx, d, cam, w, h, contiguous_rows(y0, y1), max_depth, target, d.stream)) != RT_OK) return rc;
+            if (host_gather && block > 0) {
+                if ((rc = enqueue_copy(d.out, (size_t)y0 * (size_t)w, block, d.stream)) != RT_OK) return rc;
+                if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[4], d.stream));
+            }
         }
-        // Gather: every other device writes its block into device 0's frame (one copy per
+        // Device gather: every other device writes its block into device 0's frame (one copy per
         // device, each over its own link), then one copy to the host.
-        for (int g = 1; g < G; g++) {
+        for (int g = 1; g < G && !host_gather; g++) {
             DeviceState &d = ctx->dev[g];
             const int y0 = ctx->last_rows[g], y1 = ctx->last_rows[g + 1];
             const size_t bytes = (size_t)(y1 - y0) * (size_t)w * sizeof(int32_t);
@@ -2087,20 +2255,28 @@ static int render_to_host(rt_ctx *ctx, const rt_camera *cam, int w, int h, int m
             }
         }
     }
+    if (host_gather) {
+        // The pieces arrive on G streams at once; the caller's thread takes them in the order they were enqueued.
+        if ((rc = drain_copy()) != RT_OK) return rc;
+    }
     ctx->gather_ms = 0.0;
     for (int g = G - 1; g >= 0; g--) {
         DeviceState &d = ctx->dev[g];
         HIP_TRY(ctx, hipSetDevice(d.device));
         HIP_TRY(ctx, hipStreamSynchronize(d.stream));
-        if ((g > 0 || interleaved) && d.timed && d.last_P > 0) {
-            float ms = 0.f;
+        if ((g > 0 || interleaved || host_gather) && d.timed && d.last_P > 0) {
+            float ms = 0.f;   // (host gather: the device's own copy to the host)
             if (hipEventElapsedTime(&ms, d.ev[3], d.ev[4]) == hipSuccess)
                 ctx->gather_ms = std::max(ctx->gather_ms, (double)ms);
         }
         if (d.last_P > 0 && (rc = check_schedule(ctx, d)) != RT_OK) return rc;
     }
+    if (host_gather) {
+        ctx->copy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+        return RT_OK;
+    }
     const auto t0 = std::chrono::steady_clock::now();
-    if ((rc = enqueue_copy(0, (size_t)total, root.stream)) != RT_OK) return rc;
+    if ((rc = enqueue_copy(root.out, 0, (size_t)total, root.stream)) != RT_OK) return rc;
     if ((rc = drain_copy()) != RT_OK) return rc;
     ctx->copy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;

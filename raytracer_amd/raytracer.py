@@ -141,6 +141,11 @@ class RenderContext:
         """rt_set_device_share: this many contexts render on the device at the same time."""
         self._check(self._lib.rt_set_device_share(self._ctx, int(contexts)))
 
+    def reload_tuning(self) -> None:
+        """rt_reload_tuning: read the RT_HIP_* tuning aids and test knobs from the environment again
+        (the library reads them when a context is created and when it gets a scene, not per frame)."""
+        self._check(self._lib.rt_reload_tuning(self._ctx))
+
     def frame_status(self) -> None:
         """rt_frame_status: waits for the frames enqueued with render_*_device so far and raises
         RtError (RT_ERR_STALLED) if the device gave up on one of them."""

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert getattr(lib, name) is not None, name
     header = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
-    assert lib.rt_api_version() == int(re.search(r"#define RT_API_VERSION (\d+)", header).group(1)) == 6
+    assert lib.rt_api_version() == int(re.search(r"#define RT_API_VERSION (\d+)", header).group(1)) == 7
 
 
 def test_struct_sizes_match_the_header_layout():

@@ -224,6 +224,7 @@ def test_chunk_jobs_and_tile_walks_agree_on_a_large_frame(oracle, monkeypatch):
         for below in ("", "1", "1000000"):
             if below:
                 monkeypatch.setenv("RT_HIP_SPLIT_BELOW", below)
+                c.reload_tuning()
             frames.append(c.render(Camera(), w, h, depth))
             c.frame_status()
     assert np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[2])

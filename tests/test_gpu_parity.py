@@ -420,6 +420,34 @@ def test_large_frame_rendered_in_parts_with_overlapped_copy(oracle):
     assert_parity(small, ref_small, "small frame after a frame in parts")
 
 
+@pytest.mark.parametrize("parts,bands", [("2", ""), ("3", ""), ("5", ""), ("3", "0"), ("8", "")])
+def test_row_blocks_of_any_number_and_form(monkeypatch, parts, bands):
+    """rt_render's row blocks forced on a frame whose height is no multiple of the band (a short last band that
+    falls to block 1 of 2, 1 of 3, ...): interleaved bands put in place by strided copies, contiguous blocks
+    (RT_HIP_PART_BANDS=0), into pageable memory (staged, 2 MiB pieces) and into the library's page-locked
+    framebuffer (one strided copy per block): the frame rendered in one piece, every time."""
+    fs = scene_1k().flatten()
+    cam, w, h, depth = Camera(position=(0.1, -0.2, -0.1)), 1280, 1000 + 9, 3
+    with RenderContext() as c:
+        c.set_scene(fs)
+        c.set_profiling(2)
+        whole = c.render(cam, w, h, depth)           # (profiling on: one piece)
+        c.set_profiling(0)
+        monkeypatch.setenv("RT_HIP_FRAME_PARTS", parts)
+        if bands:
+            monkeypatch.setenv("RT_HIP_PART_BANDS", bands)
+        c.reload_tuning()
+        staged = c.render(cam, w, h, depth)
+        st = c.stats()
+        assert np.array_equal(staged, whole)
+        assert st["rays_primary"] == w * h
+        fb = c.alloc_pixels(h + 2, w)
+        fb[:] = -1
+        direct = c.render(cam, w, h, depth, out=fb[1:h + 1])
+        assert np.array_equal(direct.reshape(h, w), whole)
+        assert (fb[0] == -1).all() and (fb[h + 1] == -1).all()
+
+
 @pytest.mark.parametrize("size,offset", [((1024, 768), 1), ((1024, 768), 3), ((3840, 2160), 1), ((333, 217), 2)])
 def test_framebuffer_at_any_alignment(size, offset):
     """pixels_out is whatever address the host's array has (a managed int[] is 8-byte aligned at
@@ -485,10 +513,14 @@ def test_pipeline_slots_alternate_streams_on_one_context(ctx, oracle):
         assert_parity(frames[i].cpu().numpy(), ref, f"pipelined frame {i}")
 
 
-def test_two_device_states_split_rows_and_gather(oracle):
+@pytest.mark.parametrize("host_gather", ["1", "0"])
+def test_two_device_states_split_rows_and_gather(oracle, monkeypatch, host_gather):
     """rt_create with several device entries (the same GPU several times on a one-GPU box): tall
-    frames are split into interleaved bands of 16 rows and gathered with one strided copy per
-    device (a short last band, exact bands, three devices), short frames into contiguous blocks."""
+    frames are split into interleaved bands of 16 rows and put in place with one strided copy per
+    device (a short last band, exact bands, three devices), short frames into contiguous blocks.  Every
+    device copies its rows to the host itself, into pageable memory through the staging frame and straight
+    into a page-locked framebuffer; with RT_HIP_HOST_GATHER=0 the rows first meet in the first device's frame."""
+    monkeypatch.setenv("RT_HIP_HOST_GATHER", host_gather)
     fs = default_scene().flatten()
     cam = Camera()
     with RenderContext([0, 0]) as two:
@@ -508,6 +540,20 @@ def test_two_device_states_split_rows_and_gather(oracle):
             gpu = three.render(cam, w, h, 5)
             ref, _ = oracle.render(fs, cam, w, h, max_depth=5)
             assert np.array_equal(gpu, ref), (w, h)
+            fb = three.alloc_pixels(h + 1, w)       # the direct path: every device's copy lands in the caller's frame
+            fb[:] = -1
+            assert np.array_equal(three.render(cam, w, h, 5, out=fb[:h]).reshape(h, w), ref), (w, h, "page-locked")
+            assert (fb[h] == -1).all()
+            three.unpin_pixels()
+        # a frame tall enough for several strided copies per device on the staged path (2 MiB pieces)
+        w, h = 1024, 1500
+        gpu = three.render(cam, w, h, 2)
+        ref, _ = oracle.render(fs, cam, w, h, max_depth=2, row_step=25)
+        rows = list(range(0, h, 25))
+        assert np.array_equal(gpu[rows], ref[rows])
+    with RenderContext() as one:
+        one.set_scene(fs)
+        assert np.array_equal(one.render(cam, w, h, 2), gpu)
 
 
 def test_devices_without_peer_access_hand_their_rows_over_through_the_host(oracle, monkeypatch):
@@ -515,6 +561,7 @@ def test_devices_without_peer_access_hand_their_rows_over_through_the_host(oracl
     rows travel through the page-locked staging frame (RT_HIP_NO_PEER=1 makes rt_create treat every
     other device that way).  Interleaved bands and the contiguous fallback, two and three devices."""
     monkeypatch.setenv("RT_HIP_NO_PEER", "1")
+    monkeypatch.setenv("RT_HIP_HOST_GATHER", "0")   # (by default every device copies its rows to the host itself)
     fs = default_scene().flatten()
     cam = Camera(position=(0.3, 0.1, -0.2))
     with RenderContext([0, 0]) as two:

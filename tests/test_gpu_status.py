@@ -26,6 +26,7 @@ def test_stalled_schedule_surfaces_through_every_entry(oracle, monkeypatch):
         monkeypatch.setenv("RT_HIP_PIPELINE", "fused")   # the form with a device-side schedule
         monkeypatch.setenv("RT_HIP_STALL_MS", "150")
         monkeypatch.setenv("RT_HIP_DEBUG_WITHHOLD_LEVEL", "0")
+        c.reload_tuning()
         c.render_rows_device(cam, w, h, 0, h, depth, buf.data_ptr(), stream.cuda_stream)
         with pytest.raises(RtError) as e:
             c.frame_status()
@@ -35,6 +36,7 @@ def test_stalled_schedule_surfaces_through_every_entry(oracle, monkeypatch):
             c.render(cam, w, h, depth)
         assert e.value.status == -8
         monkeypatch.delenv("RT_HIP_DEBUG_WITHHOLD_LEVEL")
+        c.reload_tuning()
         c.render_bands_device(cam, w, h, 16, 0, 1, depth, buf.data_ptr(), stream.cuda_stream)
         c.frame_status()
         assert np.array_equal(buf.cpu().numpy(), ref)
