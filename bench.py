@@ -54,7 +54,7 @@ import torch  # noqa: F401  (imported before librt_hip.so so both share one HIP 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from raytracer_amd import Camera, RenderContext, RtError, scene_1k, scene_64k  # noqa: E402
+from raytracer_amd import Camera, RenderContext, RtError, default_scene, scene_1k, scene_64k  # noqa: E402
 from raytracer_amd.distributed import FramePipeline, render_block  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3          # 256 CUs x 4 SIMDs x 64 lanes x 2 FLOP / 2 cycles x 2.4 GHz
@@ -62,15 +62,24 @@ SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 2.0
 FLOP_SPHERE, FLOP_PLANE, FLOP_TRIANGLE, FLOP_LIGHT_SHADE = 25.0, 13.0, 51.0, 80.0
 
 CONFIGS = {
+    # The reference's own scene, primary + shadow rays only (max_depth 0: no mirror recursion).
+    "c2": dict(width=1920, height=1080, max_depth=0, scene=default_scene, cpu_row_step=1, cpu_mode="literal",
+               workload="reference default scene (2 spheres, 1 triangle, 6 planes, 2 lights), 1920x1080, primary + shadow rays only",
+               pmc=None),
     # The configuration the headline metric is quoted on.
     "c3": dict(width=3840, height=2160, max_depth=4, scene=scene_1k, cpu_row_step=1, cpu_mode="literal",
                workload="synthetic 1k-sphere scene (1000 spheres + 6 planes, 2 lights), 3840x2160, 4 mirror bounces",
-               pmc="r02_c3_trace_pmc.json"),
+               pmc="r03_c3_trace_pmc.json"),
+    # The same scene at 7680x4320: the frame the row partition over 8 GPUs is specified on (one GPU renders all of it).
+    "c4": dict(width=7680, height=4320, max_depth=4, scene=scene_1k, cpu_row_step=8, cpu_mode="literal",
+               workload="synthetic 1k-sphere scene (1000 spheres + 6 planes, 2 lights), 7680x4320, 4 mirror bounces",
+               pmc=None),
     # Divergence / occupancy stress.
     "c5": dict(width=1920, height=1080, max_depth=8, scene=scene_64k, cpu_row_step=54, cpu_mode="memoised",
                workload="synthetic 64k-sphere scene (65536 spheres + 6 planes, 16 lights), 1920x1080, 8 mirror bounces",
-               pmc="r02_c5_trace_pmc.json"),
+               pmc="r03_c5_trace_pmc.json"),
 }
+WARM_SECONDS = 0.3   # untimed frames before the timed loop run at least this long: the clocks have ramped, whatever --steps
 
 
 def cpu_baseline(cfg, flat, cam) -> dict:
@@ -83,21 +92,48 @@ def cpu_baseline(cfg, flat, cam) -> dict:
     mode = O.MODE_LITERAL if cfg["cpu_mode"] == "literal" else O.MODE_MEMOISED
     threads = O.num_threads()
     t0 = time.perf_counter()
-    _, cnt = O.render(flat, cam, w, h, max_depth=depth, mode=mode, row_step=step)
-    dt = time.perf_counter() - t0
+    passes = 0
+    while passes == 0 or (time.perf_counter() - t0 < 3.0 and passes < 1000):   # (a small frame: again until it is a measurement)
+        _, cnt = O.render(flat, cam, w, h, max_depth=depth, mode=mode, row_step=step)
+        passes += 1
+    dt = (time.perf_counter() - t0) / passes
     if mode != O.MODE_MEMOISED:   # ray count of the same rows, de-duplicated like the GPU's (not timed)
         _, cnt = O.render(flat, cam, w, h, max_depth=depth, mode=O.MODE_MEMOISED, row_step=step)
     rays = cnt["rays_primary"] + cnt["rays_shadow"] + cnt["rays_secondary"]
     how = "literal per-light recursion" if mode == O.MODE_LITERAL else "memoised recursion (one trace per level)"
     return {
         "value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "sample": f"{len(range(0, h, step))} of the {h} rows (every {step}) of the {w}x{h} frame, {how}, {dt:.1f} s",
+        "sample": f"{len(range(0, h, step))} of the {h} rows (every {step}) of the {w}x{h} frame, {how}, "
+                  f"{passes} pass{'es' if passes > 1 else ''} of {dt:.2f} s",
     }
 
 
-def pmc_summary(name: str) -> dict:
+def host_handoff(config: str) -> dict:
+    """rt_render as a host WITHOUT PyTorch sees it - the C# application loads librt_hip.so against the
+    system's HIP runtime, whose device-to-host copies run on the DMA engines; the runtime inside the PyTorch
+    wheel, which this process shares with torch, makes them with a shader kernel that takes the device from
+    whatever renders beside it.  tools/handoff_host.py in a process of its own, started BEFORE this one touches
+    the GPU."""
+    import subprocess
+    env = dict(os.environ, RT_HIP_SYSTEM_RUNTIME="1", PROBE_REPS="20")
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "handoff_host.py"), config], env=env,
+                           capture_output=True, text=True, timeout=180)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        row = d["rows"][0]
+        if not (row["identical"] and row["pageable_identical"]):
+            return {"error": "frames differ between the hand-off paths"}
+        return {"rt_render_library_framebuffer_ms": row["library_framebuffer_ms"], "rt_render_pageable_ms": row["pageable_ms"],
+                "kernels_alone_ms": d["kernels_ms"], "runtime": "system HIP runtime (/opt/rocm), no PyTorch in the process"}
+    except Exception as e:   # noqa: BLE001  (a missing tool or a failed child must not cost the bench line)
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+
+
+def pmc_summary(name) -> dict:
     """Per-frame counters of the levels stage on this workload from the committed rocprofv3
     PMC passes (they cannot be collected from inside this process); {} when missing."""
+    if not name:
+        return {}
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
@@ -114,6 +150,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-handoff", action="store_true", help="skip the host hand-off measurements (N = 1)")
+    ap.add_argument("--partition", choices=["interleaved", "contiguous"], default="interleaved",
+                    help="N > 1: every N-th band of 16 rows per rank, or one block of height / N rows")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     W, H, DEPTH = cfg["width"], cfg["height"], cfg["max_depth"]
@@ -125,6 +164,8 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("RT_BENCH_ONE_GPU") else local_rank
+    # (before anything here touches the GPU: the child has the device to itself)
+    host_side = host_handoff(args.config) if world == 1 and not args.no_handoff else None
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
@@ -153,7 +194,8 @@ def main() -> None:
         c.set_scene(flat)
         c.set_device_share(in_flight)
     ctx = contexts[0]
-    pipeline = FramePipeline(W, H, rank, world, device, depth=in_flight, contexts=contexts)
+    interleave = args.partition == "interleaved"
+    pipeline = FramePipeline(W, H, rank, world, device, depth=in_flight, contexts=contexts, interleave=interleave)
 
     def step() -> None:
         pipeline.render_frame(None, cam, DEPTH)
@@ -165,6 +207,20 @@ def main() -> None:
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
+        step()
+    fence()
+    # ... and on until the device has worked for WARM_SECONDS (every rank the same number of frames: collectives)
+    t_warm = time.perf_counter()
+    for _ in range(3):
+        step()
+    fence()
+    per_frame = max((time.perf_counter() - t_warm) / 3, 1e-5)
+    more = torch.tensor([max(0.0, WARM_SECONDS / per_frame - 3)], dtype=torch.float64)
+    if dist is not None:
+        more = more.cuda() if backend == "nccl" else more
+        dist.all_reduce(more, op=dist.ReduceOp.MAX)
+    extra_warm = int(more.item())
+    for _ in range(extra_warm):
         step()
     fence()
     t0 = time.perf_counter()
@@ -202,6 +258,26 @@ def main() -> None:
     st = ctx.stats()
     ctx.set_profiling(0)
 
+    # N > 1, what a BLOCKING Render() sees (MyApplication.cs:179-193 presents every frame before it starts the
+    # next): one frame at a time - this rank's rows, the gather, the row permutation on rank 0, all ranks in
+    # step - next to the frames-in-flight figure of the timed loop; and the same with the other partition.
+    blocking = {}
+    if world > 1:
+        def one_at_a_time(pipe, frames=20) -> float:
+            for _ in range(3):
+                pipe.render_frame(ctx, cam, DEPTH)
+                fence()
+            t = time.perf_counter()
+            for _ in range(frames):
+                pipe.render_frame(ctx, cam, DEPTH)
+                fence()
+            return (time.perf_counter() - t) / frames * 1e3
+        single = FramePipeline(W, H, rank, world, device, depth=1, contexts=[ctx], interleave=interleave)
+        other = FramePipeline(W, H, rank, world, device, depth=1, contexts=[ctx], interleave=not interleave)
+        blocking = {"one_frame_at_a_time_ms": one_at_a_time(single),
+                    ("contiguous" if interleave else "interleaved") + "_partition_one_frame_at_a_time_ms": one_at_a_time(other)}
+        del single, other
+
     # Beyond the timed step: N > 1, the gather and the copy of the gathered frame to the host, each
     # timed on its own; N = 1 below (rank 0 only).
     handoff = {}
@@ -229,15 +305,16 @@ def main() -> None:
             "plane_tests", "triangle_tests", "filter_ray_tests", "filter_origin_terms", "exact_candidates",
             "primary_filter_ray_tests", "primary_exact_candidates", "shadow_candidates")
     totals = torch.tensor([float(st[k]) for k in keys], dtype=torch.float64, device="cuda")
-    times = torch.tensor([elapsed, ev["trace_ms"], ev["kernel_ms"], ev["primary_ms"], ev["shade_ms"], stalled],
-                         dtype=torch.float64, device="cuda")
+    times = torch.tensor([elapsed, ev["trace_ms"], ev["kernel_ms"], ev["primary_ms"], ev["shade_ms"], stalled] +
+                         list(blocking.values()), dtype=torch.float64, device="cuda")
     if dist is not None:
         if backend != "nccl":   # (host tensors: see FrameGatherer._gather_through_host)
             totals, times = totals.cpu(), times.cpu()
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     tot = dict(zip(keys, totals.tolist()))
-    elapsed, trace_ms, kernel_ms, primary_ms, shade_ms, stalled = times.tolist()
+    elapsed, trace_ms, kernel_ms, primary_ms, shade_ms, stalled = times.tolist()[:6]
+    blocking = dict(zip(blocking, (round(v, 4) for v in times.tolist()[6:])))
     if stalled:
         for c in contexts:
             c.close()
@@ -264,6 +341,10 @@ def main() -> None:
                          (FLOP_SPHERE + 11.0) * tr_candidates + FLOP_SPHERE * tot["shadow_candidates"] +
                          FLOP_PLANE * tr_p + FLOP_TRIANGLE * tr_t +
                          FLOP_LIGHT_SHADE * flat.num_lights * (tot["shaded_hits"] - tot["rays_secondary"]))
+        # Scenes of at most four lights, one frame at a time: the reflecting records' light terms are computed
+        # inside the stage as well (k_lit, beside the plain records' launches), one reflecting record per secondary ray.
+        if flat.num_lights <= 4 and DEPTH > 0 and in_flight == 1:
+            executed_flop += FLOP_LIGHT_SHADE * flat.num_lights * tot["rays_secondary"]
         trace_s = trace_ms * 1e-3
         # Per-GPU rate of the dominant kernel: each rank traced 1/world of the FLOP.
         executed = executed_flop / world / trace_s / 1e12 if trace_s > 0 else 0.0
@@ -275,7 +356,11 @@ def main() -> None:
                       else f"Mrays/sec (primary+secondary) at {W}x{H}",
             "value": round(rays / (ms_per_step * 1e-3) / 1e6, 2),
             "unit": "Mrays/s",
+            # `value` counts the light (shadow) rays too, as the survey defines the metric; this is the same
+            # frame rate priced at the primary and reflection (secondary) rays alone.
+            "Mrays_primary_plus_secondary": round((tot["rays_primary"] + tot["rays_secondary"]) / (ms_per_step * 1e-3) / 1e6, 2),
             "n_gpus": world, "nranks": nranks, "steps": args.steps, "warmup": args.warmup,
+            "untimed_frames_before_the_loop": args.warmup + 3 + extra_warm,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -284,7 +369,8 @@ def main() -> None:
                 "width": W, "height": H, "max_depth": DEPTH,
                 "spheres": ns, "planes": npl, "lights": flat.num_lights,
                 "partition": ("whole frame on one GPU" if world == 1 else
-                              f"every {world}th band of 16 rows per rank, {backend} gather to rank 0, "
+                              (f"every {world}th band of 16 rows per rank" if interleave else f"one block of {H}/{world} rows per rank") +
+                              f", {backend} gather to rank 0, "
                               f"{in_flight} frames in flight per rank, each in a render context of its own (a frame's "
                               "gather and the idle stretches of its level chain overlap the next frames' kernels)"),
                 "frames_in_flight": in_flight,
@@ -310,6 +396,10 @@ def main() -> None:
                                     if valu_insts and trace_s > 0 else None),
                 "valu_insts_per_launch": valu_insts,
                 "traffic": pmc.get("traffic_bytes_per_launch"), "pmc_source": pmc.get("source"),
+                "frac_basis": "FLOP the stage EXECUTED.  Priced at the Intersect calls the reference's brute-force loops make "
+                              "(25 FLOP per ray-sphere test ...), the same launch comes to `algorithmic_tflops`, several times "
+                              "the peak: the kernels never make 97 % of those tests (culling), so that figure is a speed-up "
+                              "over brute force (`algorithmic_speedup`), not a rate of the hardware, and is not used for `frac`",
                 "algorithmic_tflops": round(algorithmic, 3),
                 "algorithmic_flop_per_launch": algorithmic_flop / world,
                 "algorithmic_speedup": round(algorithmic_flop / executed_flop, 3) if executed_flop > 0 else None,
@@ -323,10 +413,10 @@ def main() -> None:
             # Render() ends with the pixels in host memory (MyApplication.cs:420): rt_render into a
             # pageable array, and into a page-locked one where the system allows registering it.
             out = np.empty((H, W), dtype=np.int32)
-            reps = 5
+            reps = 10
 
             def host_ms() -> float:
-                for _ in range(2):   # (staging buffers, events and the library's own streams are set up by the first calls)
+                for _ in range(5):   # (staging buffers, events, helper threads and the library's own streams are set up by the first calls)
                     ctx.render(cam, W, H, DEPTH, out=out)
                 t = time.perf_counter()
                 for _ in range(reps):
@@ -374,10 +464,32 @@ def main() -> None:
                                  "Mrays_per_s": round(rays / (ms2 * 1e-3) / 1e6, 2),
                                  "note": "not `value`: two render contexts on the one GPU, frames enqueued back to back "
                                          "without waiting; `value` is one frame at a time, what a blocking Render() sees"}
-            handoff = {"rt_render_pageable_ms": round(pageable, 4), "rt_render_pinned_ms": pinned,
+            # The floor of any hand-off: ONE copy of the finished frame, device -> page-locked host memory, alone.
+            dev_frame = pipeline.slots[0].frame
+            pinned_frame = torch.empty((H, W), dtype=torch.int32, pin_memory=True)
+            for _ in range(3):
+                pinned_frame.copy_(dev_frame, non_blocking=True)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(10):
+                pinned_frame.copy_(dev_frame, non_blocking=True)
+                torch.cuda.synchronize()
+            d2h_only = (time.perf_counter() - t) / 10 * 1e3
+            del pinned_frame
+            handoff = {"d2h_only_ms": round(d2h_only, 4), "d2h_GB_per_s": round(W * H * 4 / (d2h_only * 1e-3) / 1e9, 2),
+                       "host_without_pytorch": host_side,
+                       "rt_render_pageable_ms": round(pageable, 4), "rt_render_pinned_ms": pinned,
                        "rt_render_library_framebuffer_ms": owned,
-                       "note": "whole rt_render calls (kernels + copy into the caller's int[w*h]); a frame this size is "
-                               "rendered in row blocks whose copies overlap the next block's kernels"}
+                       "note": "whole rt_render calls (kernels + copy into the caller's int[w*h]); a frame of 3 M pixels or more "
+                               "is rendered as row blocks (interleaved bands) whose copies overlap the next block's kernels.  "
+                               "`host_without_pytorch`: the same calls from a process that links the system's HIP runtime, like "
+                               "the C# host (copies on the DMA engines); the other rt_render figures: this process, on the "
+                               "PyTorch wheel's runtime (copies by a shader kernel)"}
+        if blocking:
+            line["blocking"] = dict(blocking, Mrays_per_s=round(rays / (blocking["one_frame_at_a_time_ms"] * 1e-3) / 1e6, 2),
+                                    note="not `value`: one frame at a time (every rank renders its rows, gather, row permutation, "
+                                         "all ranks in step before the next frame starts) - what a blocking Render() sees on N "
+                                         "ranks; `value` keeps frames in flight")
         line["handoff"] = handoff
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, flat, cam)

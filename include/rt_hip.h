@@ -288,18 +288,22 @@ int rt_render_rows_device(rt_ctx *ctx, const rt_camera *camera, int width, int h
  * ray queues live in a fixed array of RT_NOALLOC_SCRATCH_BYTES that the library holds in every
  * GPU's memory from load to process exit, and the call makes no allocation of any kind.  The
  * frame must fit: with P = (row_end - row_begin) * width rounded up to a multiple of 64,
- *     P * (max_depth + 1) * 48 + 280 KiB  <=  RT_NOALLOC_SCRATCH_BYTES
- * (e.g. 370 x 370 pixels at max_depth 4, or 1024 x 110 at max_depth 5),
- * else RT_ERR_LIMIT and nothing is enqueued; render a taller frame as several calls of fewer
+ *     P * (max_depth + 1) * 48 + RT_NOALLOC_CONTROL_BYTES  <=  RT_NOALLOC_SCRATCH_BYTES
+ * (e.g. 370 x 370 pixels at max_depth 4, or 1024 x 110 at max_depth 5; every frame this admits is accepted),
+ * else RT_ERR_LIMIT and nothing is enqueued (rt_get_stats keeps describing the frame before); render a taller frame as several calls of fewer
  * rows.  ALL contexts of a process share a GPU's array: calls that overlap on one GPU (two
  * contexts, or two streams not ordered against each other) race on it; calls ordered one after
  * the other are independent, each clears what it needs.  The context must have been used once
  * before the no-allocation phase begins (rt_set_scene, and one render call of either kind so
  * that the runtime has loaded the kernels).
  * No counterpart in the reference (its loop allocates freely, objects.cs:125); exists for
- * callers that cannot allocate.
+ * callers that cannot allocate.  rt_get_stats after such a call reads the frame's counts out of the shared
+ * array: ask before any other context renders into it.
  */
 #define RT_NOALLOC_SCRATCH_BYTES (32u << 20)
+/* What the frame's control block (work counters, level schedule, record counts) and the alignment of the three
+ * record arrays take of the array at most. */
+#define RT_NOALLOC_CONTROL_BYTES (304u << 10)
 int rt_render_rows_device_noalloc(rt_ctx *ctx, const rt_camera *camera, int width, int height,
                                   int row_begin, int row_end, int max_depth,
                                   int32_t *dev_pixels_out, void *hip_stream);

@@ -12,6 +12,8 @@
 #include <emmintrin.h>   // SSE2 streaming stores (baseline x86-64), host pass only
 #endif
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -55,6 +57,9 @@ constexpr size_t FRAME_CONTROL_USED =
 // (rounded so that the fill that clears it is one kernel: a size that is no multiple of 16 bytes
 // gets a second fill for its tail)
 constexpr size_t FRAME_CONTROL_BYTES = (FRAME_CONTROL_USED + 255) / 256 * 256;
+static_assert(FRAME_CONTROL_BYTES + 3 * 256 <= RT_NOALLOC_CONTROL_BYTES,
+              "the fit rule rt_hip.h documents for rt_render_rows_device_noalloc must cover the control block and the "
+              "rounding of the three record arrays");
 
 // Level schedule + record counts: the part of the control block a render call leaves its
 // outcome in (has the schedule stalled, how many records did each level hold).
@@ -71,6 +76,10 @@ constexpr int RT_MAX_FRAME_PARTS = 8;
 // kernel covers 16 x 16 pixels.
 constexpr int RT_BAND_ROWS = 16;
 constexpr long long RT_MIN_SPLIT_PIXELS = 3000000, RT_PART_PIXELS = 4000000;
+// Helper threads that share the host-side move of a staged frame with the caller's thread, for frames of at
+// least so many pixels (a smaller frame's move is over before a sleeping thread has woken up).
+constexpr int RT_MOVER_THREADS = 3, RT_MAX_MOVER_THREADS = 15;
+constexpr long long RT_MOVERS_MIN_PIXELS = 1500000;
 
 // Messages live in fixed buffers so that reporting a failure can never itself fail.
 constexpr size_t RT_ERROR_CHARS = 512;
@@ -160,6 +169,7 @@ struct Tuning {
     int frame_parts = 0;         // RT_HIP_FRAME_PARTS: row blocks of rt_render's frame on one device
     int part_bands = -1;         // RT_HIP_PART_BANDS=0: contiguous row blocks instead of interleaved bands
     int host_gather = -1;        // RT_HIP_HOST_GATHER=0: several devices gather on the first one before the copy to the host
+    int mover_threads = -1;      // RT_HIP_MOVER_THREADS: helper threads of a staged frame's host-side move (0: the caller alone)
     bool handoff_trace = false;  // RT_HIP_HANDOFF_TRACE (set before the first frame): rt_render prints, per row block, when the
                                  // host enqueued it and when the device finished its kernels and its copy
 };
@@ -193,15 +203,22 @@ Tuning read_tuning()
     t.frame_parts = (int)num("RT_HIP_FRAME_PARTS", 0);
     t.part_bands = (int)num("RT_HIP_PART_BANDS", -1);
     t.host_gather = (int)num("RT_HIP_HOST_GATHER", -1);
+    t.mover_threads = (int)num("RT_HIP_MOVER_THREADS", -1);
     t.handoff_trace = getenv("RT_HIP_HANDOFF_TRACE") != nullptr;
     return t;
 }
 
 }  // namespace
 
-// Pixels per chunk of rt_render's staged device-to-host copy (2 MiB: a chunk's DMA takes ~40 us,
-// long enough to amortise its launch, short enough that the last chunk's host copy is brief).
-#define RT_STAGED_COPY_CHUNK_PIXELS ((size_t)512 * 1024)
+// Pixels per piece of rt_render's staged device-to-host copy (4 MiB: a piece's DMA takes ~75 us, long
+// enough to amortise its start - 3840x2160 into pageable memory 1.47 ms with pieces of 1 MiB, 1.24 with 2, 1.20
+// with 4, 1.27 with 8 -; the last pieces of a frame are a quarter of that, so that the move of the last
+// one, which nothing overlaps, is brief).
+#define RT_STAGED_COPY_CHUNK_PIXELS ((size_t)1024 * 1024)
+
+namespace {
+class HostMovers;
+}
 
 struct rt_ctx {
     std::vector<DeviceState> dev;
@@ -218,6 +235,7 @@ struct rt_ctx {
     std::vector<hipEvent_t> copy_ev;   // one per chunk of the framebuffer copy to the host (device 0)
     hipStream_t copy_stream = nullptr; // carries those copies while device 0's stream renders the next part
     hipEvent_t part_ev[RT_MAX_FRAME_PARTS] = {};
+    HostMovers *movers = nullptr;      // helper threads of the staged copy's host-side move (created on first use)
     hipEvent_t trace_ev = nullptr;   // RT_HIP_HANDOFF_TRACE: start of the frame on the device
     int32_t *pinned = nullptr;     // the host's own framebuffer, page-locked by rt_pin_pixels
     void *pinned_base = nullptr;   // start of the registered pages
@@ -284,6 +302,85 @@ void copy_streaming(void *dst_v, const void *src_v, size_t bytes)
 }
 void store_fence() { _mm_sfence(); }
 #endif
+
+// Helper threads that move a staged frame's pieces from the page-locked staging frame into the caller's pageable
+// array beside the calling thread: one thread moves ~27 GB/s with streaming stores, the DMA brings 55, so a frame
+// that is staged is bound by the move unless it is shared (3840x2160: 1.35 ms with one thread).  The threads are
+// started with the first large staged frame, sleep between frames and end with the context.  A system that gives
+// no thread leaves the move to the caller alone.
+class HostMovers {
+public:
+    ~HostMovers()
+    {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread &t : threads_)
+            if (t.joinable()) t.join();
+    }
+    // Threads available beside the caller (starts them on first use; never throws).
+    int helpers(int wanted) noexcept
+    {
+        while ((int)threads_.size() < wanted) {
+            try {
+                const int id = (int)threads_.size() + 1;
+                threads_.emplace_back([this, id] { loop(id); });
+            } catch (...) {
+                break;   // (no thread to be had: the caller moves more itself)
+            }
+        }
+        return (int)threads_.size();
+    }
+    // Runs job(worker, workers) on the caller (worker 0) and on every helper; returns when all are done.
+    void run(const std::function<void(int, int)> &job)
+    {
+        const int workers = (int)threads_.size() + 1;
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            job_ = &job;
+            workers_ = workers;
+            pending_.store(workers - 1, std::memory_order_relaxed);
+            generation_++;
+        }
+        cv_.notify_all();
+        job(0, workers);
+        while (pending_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+        std::lock_guard<std::mutex> lock(m_);
+        job_ = nullptr;
+    }
+
+private:
+    void loop(int id)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int, int)> *job = nullptr;
+            int workers = 0;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                cv_.wait(lock, [&] { return quit_ || generation_ != seen; });
+                if (quit_) return;
+                seen = generation_;
+                job = job_;
+                workers = workers_;
+            }
+            if (job && id < workers) {
+                (*job)(id, workers);
+                pending_.fetch_sub(1, std::memory_order_release);
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    const std::function<void(int, int)> *job_ = nullptr;
+    int workers_ = 0;
+    uint64_t generation_ = 0;
+    bool quit_ = false;
+    std::atomic<int> pending_{0};
+};
 
 #define HIP_TRY(ctx, expr)                                                                  \
     do {                                                                                    \
@@ -666,6 +763,33 @@ int light_table_bins(size_t spheres)
     return spheres <= 256 ? 32 : spheres <= 4096 ? 64 : spheres <= 262144 ? 128 : 256;
 }
 
+// Jobs 0 .. jobs - 1, each exactly once, on up to `workers` threads: the calling thread is one of them, and it
+// does all the work itself when the system gives no further thread.  Every thread that was started is joined
+// before this returns or throws; a job must not throw.
+template <class Job>
+void run_jobs(size_t jobs, size_t workers, Job &&job)
+{
+    std::atomic<size_t> next{0};
+    auto drain = [&] {
+        for (size_t k = next.fetch_add(1); k < jobs; k = next.fetch_add(1)) job(k);
+    };
+    struct Joiner {
+        std::vector<std::thread> pool;
+        ~Joiner()
+        {
+            for (std::thread &t : pool)
+                if (t.joinable()) t.join();
+        }
+    } joiner;
+    try {
+        joiner.pool.reserve(workers);
+        for (size_t w = 1; w < workers; w++) joiner.pool.emplace_back(drain);
+    } catch (...) {
+        // (thread or process limit reached: the threads that did start share the jobs with this one)
+    }
+    drain();
+}
+
 void build_light_tables(PackedScene &out)
 {
     const size_t ns = out.sph.size(), nl = out.light_pos.size();
@@ -811,15 +935,7 @@ void build_light_tables(PackedScene &out)
     // lists) first.
     const size_t jobs = tiers * nl;
     const size_t workers = std::max<size_t>(1, std::min<size_t>({jobs, (size_t)std::thread::hardware_concurrency(), 16}));
-    {
-        std::atomic<size_t> next{0};
-        std::vector<std::thread> pool;
-        for (size_t w = 0; w < workers; w++)
-            pool.emplace_back([&] {
-                for (size_t k = next.fetch_add(1); k < jobs; k = next.fetch_add(1)) one_light(jobs - 1 - k);
-            });
-        for (std::thread &t : pool) t.join();
-    }
+    run_jobs(jobs, workers, [&](size_t k) { one_light(jobs - 1 - k); });
     for (const PerLight &pl : per)
         if (pl.failed) throw std::bad_alloc();
     size_t total = 0;
@@ -850,15 +966,7 @@ void build_light_tables(PackedScene &out)
             c.y++;
         }
     };
-    {
-        std::atomic<size_t> next{0};
-        std::vector<std::thread> pool;
-        for (size_t w = 0; w < workers; w++)
-            pool.emplace_back([&] {
-                for (size_t k = next.fetch_add(1); k < jobs; k = next.fetch_add(1)) fill(jobs - 1 - k);
-            });
-        for (std::thread &t : pool) t.join();
-    }
+    run_jobs(jobs, workers, [&](size_t k) { fill(jobs - 1 - k); });
     out.lt_n = n;
     out.lt_near = (float)(near * (1.0 - 1e-6));
     out.lt_tiers = (int)tiers;
@@ -1821,6 +1929,7 @@ void rt_destroy(rt_ctx *ctx)
     for (hipEvent_t e : ctx->part_ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->trace_ev) (void)hipEventDestroy(ctx->trace_ev);
+    delete ctx->movers;
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->pinned) (void)(ctx->pinned_owned ? hipHostFree(ctx->pinned_base) : hipHostUnregister(ctx->pinned_base));
     delete ctx;
@@ -2046,24 +2155,42 @@ static int render_to_host(rt_ctx *ctx, const rt_camera *cam, int w, int h, int m
     };
     // Enqueues the copy of the frame's pixels [off, off + count) from src (which holds them in frame order).
     auto enqueue_copy = [&](const int32_t *src, size_t off, size_t count, hipStream_t stream) -> int {
-        for (size_t o = off; o < off + count; o += chunk) {
-            const size_t len = std::min(chunk, off + count - o);
+        for (size_t o = off, len = 0; o < off + count; o += len) {
+            // (the frame's last pieces are smaller)
+            len = std::min(!direct && o + chunk >= (size_t)total ? std::max<size_t>(chunk / 4, 1) : chunk, off + count - o);
             HIP_TRY(ctx, hipMemcpyAsync(host + o, src + (o - off), len * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             int r = piece_event(stream, Piece{o, len, len, 1});
             if (r != RT_OK) return r;
         }
         return RT_OK;
     };
-    // Waits for the pieces in order and, when staged, moves each on into the caller's array.
+    // Waits for the pieces in order and, when staged, moves each on into the caller's array - large frames with
+    // helper threads beside the caller's (worker t of T takes the pieces t, t + T, ...; RT_HIP_MOVER_THREADS).
     auto drain_copy = [&]() -> int {
-        for (size_t k = 0; k < pieces.size(); k++) {
-            HIP_TRY(ctx, hipEventSynchronize(ctx->copy_ev[k]));
-            if (!direct)
-                for (size_t r = 0; r < pieces[k].runs; r++)
-                    copy_streaming(pixels_out + pieces[k].off + r * pieces[k].stride, ctx->staging + pieces[k].off + r * pieces[k].stride,
-                                   pieces[k].len * sizeof(int32_t));
-        }
-        if (!direct) store_fence();   // the streaming stores are visible before the call returns
+        const int wanted = direct || total < RT_MOVERS_MIN_PIXELS ? 0
+                           : std::min(tune.mover_threads >= 0 ? tune.mover_threads : RT_MOVER_THREADS, RT_MAX_MOVER_THREADS);
+        if (wanted > 0 && !ctx->movers) ctx->movers = new (std::nothrow) HostMovers();
+        const int helpers = wanted > 0 && ctx->movers ? ctx->movers->helpers(wanted) : 0;
+        std::atomic<int> failed{(int)hipSuccess};
+        const int device = root.device;
+        auto work = [&](int worker, int workers) {
+            if (worker > 0) (void)hipSetDevice(device);
+            for (size_t k = (size_t)worker; k < pieces.size(); k += (size_t)workers) {
+                const hipError_t e = hipEventSynchronize(ctx->copy_ev[k]);
+                if (e != hipSuccess) {
+                    failed.store((int)e);
+                    break;
+                }
+                if (!direct)
+                    for (size_t r = 0; r < pieces[k].runs; r++)
+                        copy_streaming(pixels_out + pieces[k].off + r * pieces[k].stride,
+                                       ctx->staging + pieces[k].off + r * pieces[k].stride, pieces[k].len * sizeof(int32_t));
+            }
+            if (!direct) store_fence();   // this thread's streaming stores are visible before the call returns
+        };
+        if (helpers > 0) ctx->movers->run(work);
+        else work(0, 1);
+        HIP_TRY(ctx, (hipError_t)failed.load());
         return RT_OK;
     };
 
@@ -2118,8 +2245,9 @@ static int render_to_host(rt_ctx *ctx, const rt_camera *cam, int w, int h, int m
                 // (a staged frame's bands go in several strided copies, so that the caller's thread moves the first
                 // ones on while the later ones travel)
                 const int step = direct ? std::max(1, full) : std::max(1, (int)(chunk / band_px));
-                for (int b = 0; b < full; b += step) {
-                    const int n = std::min(step, full - b);
+                for (int b = 0, n = 0; b < full; b += n) {
+                    // (the frame's last pieces are smaller)
+                    n = std::min(p == parts - 1 && b + step >= full ? std::max(1, step / 4) : step, full - b);
                     const size_t first = ((size_t)b * (size_t)parts + (size_t)p) * band_px;   // the frame's pixel the copy starts at
                     HIP_TRY(ctx, hipMemcpy2DAsync(host + first, (size_t)parts * band_px * sizeof(int32_t), src + (size_t)b * band_px,
                                                   band_px * sizeof(int32_t), band_px * sizeof(int32_t), (size_t)n,

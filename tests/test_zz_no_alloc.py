@@ -53,3 +53,23 @@ def test_noalloc_entry_matches_the_allocating_one_twice_in_a_row(oracle):
         c.render_rows_device_noalloc(cam, 1024, 1024, 0, 64, 4, big.data_ptr(), stream.cuda_stream)   # fewer rows fit
         c.frame_status()
         assert big[:64].any().item()
+
+
+def test_the_largest_frame_the_documented_rule_admits_is_accepted():
+    """P * (max_depth + 1) * 48 + RT_NOALLOC_CONTROL_BYTES <= RT_NOALLOC_SCRATCH_BYTES (include/rt_hip.h): the
+    largest P that satisfies it renders, and renders the frame of the allocating entry."""
+    import os
+    import re
+    import torch
+    header = open(os.path.join(os.path.dirname(__file__), "..", "include", "rt_hip.h")).read()
+    scratch = int(re.search(r"#define RT_NOALLOC_SCRATCH_BYTES \((\d+)u << 20\)", header).group(1)) << 20
+    control = int(re.search(r"#define RT_NOALLOC_CONTROL_BYTES \((\d+)u << 10\)", header).group(1)) << 10
+    depth, w = 4, 64
+    rows = (scratch - control) // (48 * (depth + 1)) // w          # P = rows * 64: a multiple of 64 as it is
+    assert (rows + 1) * w * (depth + 1) * 48 + control > scratch
+    stream = torch.cuda.Stream()
+    fs, cam = scene_1k().flatten(), Camera()
+    with RenderContext() as c:
+        c.set_scene(fs)
+        got, want = _both_ways(c, cam, w, rows, 0, rows, depth, stream)
+        assert np.array_equal(got, want)

@@ -20,7 +20,7 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-STAGE = ("k_reflect", "k_plain", "k_trace_levels", "k_shade_lights")
+STAGE = ("k_reflect", "k_plain", "k_trace_levels", "k_shade_lights", "k_lit", "k_bin_")
 
 
 def short(name: str) -> str:
@@ -70,7 +70,7 @@ def span(path: str, frames: int) -> None:
 
 def pmc(out: str, passes) -> None:
     result = {"kernels": "the launches of a frame between k_primary and the first k_shade: k_reflect / k_reflect_chunks / "
-                         "k_reflect_finish, k_plain / k_shade_lights (or k_trace_levels)", "per": "frame"}
+                         "k_reflect_finish, k_plain / k_plain_tail / k_shade_lights / k_lit / k_bin_* (or k_trace_levels)", "per": "frame"}
     for spec in passes:
         label, path = spec.split("=", 1)
         acc, frames = defaultdict(float), set()
