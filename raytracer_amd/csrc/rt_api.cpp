@@ -169,6 +169,7 @@ struct Tuning {
     int frame_parts = 0;         // RT_HIP_FRAME_PARTS: row blocks of rt_render's frame on one device
     int part_bands = -1;         // RT_HIP_PART_BANDS=0: contiguous row blocks instead of interleaved bands
     int host_gather = -1;        // RT_HIP_HOST_GATHER=0: several devices gather on the first one before the copy to the host
+    int aux_priority = -1;       // RT_HIP_AUX_PRIORITY=0 (read by rt_create): the second stream at the ordinary priority
     int mover_threads = -1;      // RT_HIP_MOVER_THREADS: helper threads of a staged frame's host-side move (0: the caller alone)
     bool handoff_trace = false;  // RT_HIP_HANDOFF_TRACE (set before the first frame): rt_render prints, per row block, when the
                                  // host enqueued it and when the device finished its kernels and its copy
@@ -203,6 +204,7 @@ Tuning read_tuning()
     t.frame_parts = (int)num("RT_HIP_FRAME_PARTS", 0);
     t.part_bands = (int)num("RT_HIP_PART_BANDS", -1);
     t.host_gather = (int)num("RT_HIP_HOST_GATHER", -1);
+    t.aux_priority = (int)num("RT_HIP_AUX_PRIORITY", -1);
     t.mover_threads = (int)num("RT_HIP_MOVER_THREADS", -1);
     t.handoff_trace = getenv("RT_HIP_HANDOFF_TRACE") != nullptr;
     return t;
@@ -423,21 +425,6 @@ void free_frame(DeviceState &d)
     d.frame = DevFrame{};
     d.out = nullptr;
     d.cap_slots = d.cap_out = 0;
-}
-
-template <typename T>
-int upload(rt_ctx *ctx, DeviceState &d, const std::vector<T> &host, const T **dev_out)
-{
-    // Never a zero-byte allocation: kernels index element 0 only when a count says so,
-    // but a non-null pointer keeps every launch argument well formed.
-    size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
-    void *p = nullptr;
-    HIP_TRY(ctx, hipMalloc(&p, bytes));
-    d.scene_allocs.push_back(p);
-    if (!host.empty())
-        HIP_TRY(ctx, hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
-    *dev_out = static_cast<const T *>(p);
-    return RT_OK;
 }
 
 struct PackedScene {
@@ -1271,6 +1258,41 @@ int pack_scene(rt_ctx *ctx, const rt_scene *s, PackedScene &out)
     return RT_OK;
 }
 
+// The arrays of a scene on their way to one device allocation (upload_scene).
+struct SceneSlab {
+    struct Item {
+        const void *src;
+        size_t bytes, offset;
+        const void **dst;
+    };
+    std::vector<Item> items;
+    size_t total = 0;
+    template <typename T>
+    void add(const std::vector<T> &host, const T **dev_out)
+    {
+        // Never an empty array: kernels index element 0 only when a count says so, but a pointer into the
+        // allocation keeps every launch argument well formed.
+        const size_t bytes = host.size() * sizeof(T), room = std::max<size_t>(bytes, 16);
+        const size_t align = room >= ((size_t)2 << 20) ? (size_t)2 << 20 : 4096;
+        total = (total + align - 1) / align * align;
+        items.push_back(Item{host.data(), bytes, total, reinterpret_cast<const void **>(dev_out)});
+        total += room;
+    }
+    int upload(rt_ctx *ctx, DeviceState &d)
+    {
+        char *base = nullptr;
+        const size_t slack = (size_t)2 << 20;
+        HIP_TRY(ctx, hipMalloc((void **)&base, total + slack));
+        d.scene_allocs.push_back(base);
+        char *start = reinterpret_cast<char *>(((uintptr_t)base + slack - 1) / slack * slack);
+        for (const Item &it : items) {
+            if (it.bytes) HIP_TRY(ctx, hipMemcpy(start + it.offset, it.src, it.bytes, hipMemcpyHostToDevice));
+            *it.dst = start + it.offset;
+        }
+        return RT_OK;
+    }
+};
+
 int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int nl)
 {
     HIP_TRY(ctx, hipSetDevice(d.device));
@@ -1284,35 +1306,40 @@ int upload_scene(rt_ctx *ctx, DeviceState &d, const PackedScene &ps, int n, int 
     sc.nt = (int)ps.tri_orig.size();
     sc.nl = nl;
     sc.nprims = n;
-    int rc;
-    if ((rc = upload(ctx, d, ps.sph, &sc.sph)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.sph_f, &sc.sph_f)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.grp_f, &sc.grp_f)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.sup_f, &sc.sup_f)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.chk_f, &sc.chk_f)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.sup_b, &sc.sup_b)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.chk_b, &sc.chk_b)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.sph_orig, &sc.sph_orig)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.pl, &sc.pl)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.pl_orig, &sc.pl_orig)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.tri, &sc.tri)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.tri_orig, &sc.tri_orig)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.geo, &sc.geo)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.mat, &sc.mat)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.light_pos, &sc.light_pos)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.light_col, &sc.light_col)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.class_prefix, &sc.class_prefix)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.lt_cells, &sc.lt_cells)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.lt_sph, &sc.lt_sph)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.lt_orig, &sc.lt_orig)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.lt_reach, &sc.lt_reach)) != RT_OK) return rc;
+    // Every array of the scene lies in ONE allocation, each at a multiple of 2 MiB or (small ones) 4 KiB from its
+    // 2 MiB-aligned start: where the tables land relative to one another and to page boundaries is the same
+    // whatever the process allocated and freed before (and rt_set_scene makes one hipMalloc instead of 27).
+    SceneSlab slab;
+    slab.add(ps.sph, &sc.sph);
+    slab.add(ps.sph_f, &sc.sph_f);
+    slab.add(ps.grp_f, &sc.grp_f);
+    slab.add(ps.sup_f, &sc.sup_f);
+    slab.add(ps.chk_f, &sc.chk_f);
+    slab.add(ps.sup_b, &sc.sup_b);
+    slab.add(ps.chk_b, &sc.chk_b);
+    slab.add(ps.sph_orig, &sc.sph_orig);
+    slab.add(ps.pl, &sc.pl);
+    slab.add(ps.pl_orig, &sc.pl_orig);
+    slab.add(ps.tri, &sc.tri);
+    slab.add(ps.tri_orig, &sc.tri_orig);
+    slab.add(ps.geo, &sc.geo);
+    slab.add(ps.mat, &sc.mat);
+    slab.add(ps.light_pos, &sc.light_pos);
+    slab.add(ps.light_col, &sc.light_col);
+    slab.add(ps.class_prefix, &sc.class_prefix);
+    slab.add(ps.lt_cells, &sc.lt_cells);
+    slab.add(ps.lt_sph, &sc.lt_sph);
+    slab.add(ps.lt_orig, &sc.lt_orig);
+    slab.add(ps.lt_reach, &sc.lt_reach);
+    slab.add(ps.gr_cells, &sc.gr_cells);
+    slab.add(ps.gr_sph, &sc.gr_sph);
+    slab.add(ps.gr_orig, &sc.gr_orig);
+    int rc = slab.upload(ctx, d);
+    if (rc != RT_OK) return rc;
     sc.lt_n = ps.lt_n;
     sc.lt_near = ps.lt_near;
     sc.lt_tiers = ps.lt_tiers;
     for (int k = 0; k < RT_LT_TIERS - 1; k++) sc.lt_tier_q[k] = ps.lt_tier_q[k];
-    if ((rc = upload(ctx, d, ps.gr_cells, &sc.gr_cells)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.gr_sph, &sc.gr_sph)) != RT_OK) return rc;
-    if ((rc = upload(ctx, d, ps.gr_orig, &sc.gr_orig)) != RT_OK) return rc;
     sc.gr_tier_t = ps.gr_tier_t;
     for (int k = 0; k < 3; k++) {
         sc.gr_n[k] = ps.gr_n[k];
@@ -1403,11 +1430,26 @@ hipError_t scratch_address(int device, unsigned char **out)
 
 
 // Streams, events, the status block and the fixed scratch's address of one device state (the device is current).
-hipError_t create_device_objects(DeviceState &d)
+// aux_low_priority: the second stream is created at the lowest stream priority.  Not for the priority's sake (the
+// plain records' launches may well yield to the chain's) but for the hardware queue: the runtime maps every stream
+// of a process onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), by priority class, and two streams
+// that share a queue run one after the other.  A caller's stream that lands on the second stream's queue costs
+// the frame its overlap of chain and plain launches - the 64k-sphere scene 3.71 instead of 2.61 ms in a process
+// whose fourth stream carried the frames - and a stream of another priority class can share no queue with it.
+hipError_t create_device_objects(DeviceState &d, bool aux_low_priority)
 {
     hipError_t e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
     for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipEventCreate(&d.ev[k]);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.aux, hipStreamNonBlocking);
+    int least = 0, greatest = 0;
+    if (e == hipSuccess && aux_low_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+        e = hipStreamCreateWithPriority(&d.aux, hipStreamNonBlocking, least);
+        if (e != hipSuccess) {   // (no such stream to be had: an ordinary one)
+            (void)hipGetLastError();
+            d.aux = nullptr;
+            e = hipSuccess;
+        }
+    }
+    if (e == hipSuccess && !d.aux) e = hipStreamCreateWithFlags(&d.aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming);
     for (int k = 0; k <= RT_MAX_DEPTH && e == hipSuccess; k++) e = hipEventCreateWithFlags(&d.ev_level[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void **)&d.status, 64, hipHostMallocMapped);
@@ -1886,7 +1928,7 @@ int rt_create(rt_ctx **out, const int *device_ids, int n_devices)
             rt_destroy(ctx);
             return rc;
         }
-        if (e == hipSuccess) e = create_device_objects(d);
+        if (e == hipSuccess) e = create_device_objects(d, ctx->tune.aux_priority != 0);
         if (e != hipSuccess) {
             int rc = fail(nullptr, RT_ERR_HIP, "device %d setup failed: %s", d.device, hipGetErrorString(e));
             rt_destroy(ctx);
