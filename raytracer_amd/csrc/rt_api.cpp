@@ -157,6 +157,7 @@ struct Tuning {
     bool level_kernels = false;  // RT_HIP_LEVEL_KERNELS: "levels" on ONE stream (a kernel trace then shows what each launch costs alone)
     int split_chunks = -1;       // RT_HIP_SPLIT_CHUNKS=0: a tile's chunks stay with its own workgroup
     int split_below = 0;         // RT_HIP_SPLIT_BELOW=n
+    int grid_split_below = -1;   // RT_HIP_GRID_SPLIT_BELOW=n (0 = never)
     int spread_below = -1;       // RT_HIP_SPREAD_BELOW=n (0 = never)
     int light_split_below = -1;  // RT_HIP_LIGHT_SPLIT_BELOW=n (0 = never)
     int light_waves = 0;         // RT_HIP_LIGHT_WAVES=1..16
@@ -189,6 +190,7 @@ Tuning read_tuning()
     t.level_kernels = getenv("RT_HIP_LEVEL_KERNELS") != nullptr;
     t.split_chunks = (int)num("RT_HIP_SPLIT_CHUNKS", -1);
     t.split_below = (int)num("RT_HIP_SPLIT_BELOW", 0);
+    t.grid_split_below = (int)num("RT_HIP_GRID_SPLIT_BELOW", -1);
     t.spread_below = (int)num("RT_HIP_SPREAD_BELOW", -1);
     t.light_split_below = (int)num("RT_HIP_LIGHT_SPLIT_BELOW", -1);
     t.light_waves = (int)num("RT_HIP_LIGHT_WAVES", 0);
@@ -1700,6 +1702,13 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // to its own workgroup.
     fr.split_chunks = !fused && !grid && tune.split_chunks != 0 && d.scene.ns_padded > RT_CHUNK ? 1 : 0;
     fr.split_below = tune.split_below > 0 ? tune.split_below : std::max(1, d.num_cus * 2 / share);
+    // Scenes with a grid, one launch per level: levels that cannot fill the device walk every ray in segments
+    // (k_reflect_grid).  RT_HIP_GRID_SPLIT_BELOW=n (tuning aid; 0 = never).  Alone on the device the 64k-sphere
+    // scene's levels 2 - 7 take 103, 54, 38, 36, 34, 32 us instead of 129, 131, 140, 114, 99, 95; the 1920x1080 frame
+    // keeps the device busy with the plain records' shading beside the chain and gains nothing (2.63 ms either way
+    // with a bound of 32768, 2.66 with 131072), smaller frames and a rank's share of a frame do: 1280x720 2.15 -> 1.88
+    // ms, 960x540 1.84 -> 1.63, one eighth of the 1920x1080 frame 1.36 -> 1.08.
+    fr.grid_split_below = !grid || fused ? 0 : tune.grid_split_below >= 0 ? tune.grid_split_below : 32768 / share;
     // Scenes of one chunk, one launch per level: a level with fewer reflecting tiles than this is traced 64
     // records per workgroup, the scene spread over the workgroup's waves.  RT_HIP_SPREAD_BELOW=n (tuning
     // aid; 0 = never).

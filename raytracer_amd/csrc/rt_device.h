@@ -239,6 +239,8 @@ struct DevFrame {
     int light_split_below; // over that many waves per 64 records (k_shade_lights)
     int spread_below;      // one-chunk scenes: levels with fewer reflecting tiles than this take 64 records per workgroup
                            // and spread the scene over its waves (k_reflect)
+    int grid_split_below;  // scenes with a grid: a level of fewer reflecting records than this has every ray's walk cut
+                           // into segments, about this many walks in all (0: never)
     int split_chunks;      // 1: levels with fewer than split_below reflecting tiles are traced one (tile, chunk)
     int split_below;       // job at a time (k_reflect_chunks): new reflecting records get their closest-hit word
                            // initialised in refl[]

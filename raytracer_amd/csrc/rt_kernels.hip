@@ -2265,17 +2265,30 @@ __global__ void __launch_bounds__(256) k_reflect_finish(DevScene s, DevFrame f, 
 //     evaluation on the spot.  The kept candidate gets its literal evaluation once, when the lane's
 //     walk is over, together with the other lanes that finished since the last refill.
 // Origins outside the region the lists were built for evaluate every sphere of the scene.
+//
+// Small levels are as long as their longest walk - up to ~150 cells, one memory round trip each, ~100 us however
+// few the rays - while nearly all lanes of the device idle.  There a ray's walk is cut into `segs` SEGMENTS of its
+// parameter range [entry into the grid, exit or closest plane hit], each walked by a lane of its own: segment k
+// starts at the cell that holds the point at the segment's start (a hundredth of a cell early, so that rounding
+// cannot open a gap between two segments' cells) and ends after the first cell the ray leaves beyond the segment's
+// end.  Every cell the ray crosses is visited by the segment its entry parameter falls into, every candidate is a
+// true hit of the ray, and the lanes' results meet in a 64-bit minimum of (t, host index): the lexicographic
+// minimum over everything evaluated, as before.  A segment that starts behind a hit already found is not walked.
 // ---------------------------------------------------------------------------------------
 #define GRID_TILE_MAX 512
+#define GRID_SEGS_MAX 8
 #ifndef GRID_REFILL_BELOW
 #define GRID_REFILL_BELOW 32
 #endif
 struct GridLds {
-    float t[GRID_TILE_MAX];       // per record of the tile: the closest hit's t,
-    int prim[GRID_TILE_MAX];      //   its host index (INT_MAX: none),
+    // per record of the tile: the closest hit as bits(t) << 32 | host index (t > 0, so the order of the keys is the
+    // order Scene.Intersect's strict `<` implies; no hit: t = FLT_MAX, index INT_MAX), merged with a 64-bit minimum
+    // when several lanes walk parts of one ray,
+    unsigned long long key[GRID_TILE_MAX];
     float dx[GRID_TILE_MAX], dy[GRID_TILE_MAX], dz[GRID_TILE_MAX];   // and the mirror direction
-    unsigned next;                // records of the tile handed out so far
+    unsigned next;                // walks of the tile handed out so far
 };
+#define GRID_NO_HIT_KEY (((unsigned long long)0x7F7FFFFFu << 32) | 0x7FFFFFFFull)   // (FLT_MAX, INT_MAX)
 
 // Sphere.Intersect objects.cs:112-121, literally; false: no hit the reference accepts.
 __device__ __forceinline__ bool grid_exact(const float4 sp, const f3 o, const f3 d, const float a, float &t)
@@ -2347,13 +2360,18 @@ __device__ __forceinline__ void grid_slab(const float g, const float dg, const f
 // and the next level's records they create.  Every thread of the workgroup must call it.
 // THROUGH: the records are read and written within one launch by several XCDs (k_trace_levels); otherwise
 // a launch per level.
+// segs: walks per ray (1: the whole ray; count * segs <= GRID_TILE_MAX * GRID_SEGS_MAX).
 template <bool COUNT, bool THROUGH>
 __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const DevFrame &f, GridLds &G, int *blk,
-                                                     const int level, const int first, const int count, TestCount &tc)
+                                                     const int level, const int first, const int count, TestCount &tc,
+                                                     const int segs = 1)
 {
     const int lane = threadIdx.x & 63;
     if (threadIdx.x == 0) G.next = 0u;
+    for (int j = threadIdx.x; j < count; j += blockDim.x) G.key[j] = GRID_NO_HIT_KEY;
     __syncthreads();
+    const int walks = count * segs;
+    float seg_end = RT_FLT_MAX;   // a walk of a segment ends after the first cell the ray leaves at or beyond this
     const int n0 = s.gr_n[0], n1 = s.gr_n[1], n2 = s.gr_n[2], ncells = n0 * n1 * n2;
     float leave = 0.f;   // parameter at which the ray leaves its current cell
     int state = GRID_EMPTY, my = 0, left = 0, cell = 0;
@@ -2376,9 +2394,10 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
                     const f3 op = sub3(o, xyz(sp));
                     (void)sphere_root(dot3(d, op), dot3(op, op) - sp.w, a, t);   // (a hit: its bracket lies above epsilon)
                 }
-                G.t[my] = t;
-                G.prim[my] = best.prim;
-                G.dx[my] = d.x, G.dy[my] = d.y, G.dz[my] = d.z;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)best.prim;
+                if (segs == 1) G.key[my] = key;
+                else if (best.prim != INT_MAX) atomicMin(&G.key[my], key);
+                G.dx[my] = d.x, G.dy[my] = d.y, G.dz[my] = d.z;   // (every segment of a ray writes the same direction)
                 state = GRID_EMPTY;
             }
             // ---- new rays for the idle lanes ----
@@ -2387,10 +2406,12 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
                 unsigned base = 0u;
                 if (lane == 0) base = atomicAdd(&G.next, (unsigned)__popcll(idle));
                 base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                exhausted = base + (unsigned)__popcll(idle) >= (unsigned)count;
+                exhausted = base + (unsigned)__popcll(idle) >= (unsigned)walks;
                 const int mine = (int)base + __popcll(idle & ((1ull << lane) - 1ull));
-                if (state == GRID_EMPTY && mine < count) {
-                    my = mine;
+                if (state == GRID_EMPTY && mine < walks) {
+                    // (the first segments of all the tile's rays are handed out first)
+                    const int seg = segs == 1 ? 0 : mine / count;
+                    my = segs == 1 ? mine : mine - seg * count;
                     const int slot = level * f.P + first + my;
                     float4 ra, rb;
                     if (THROUGH) load_record(&f.recA[slot], &f.recB[slot], ra, rb);
@@ -2420,15 +2441,15 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
                     const bool served = o.x >= s.gr_reg_lo[0] && o.x <= s.gr_reg_hi[0] && o.y >= s.gr_reg_lo[1] &&
                                         o.y <= s.gr_reg_hi[1] && o.z >= s.gr_reg_lo[2] && o.z <= s.gr_reg_hi[2];
                     if (!served) {
-                        // An origin the lists were not built for: every sphere of the scene.
-                        for (int i = 0; i < s.ns_padded; i++) {
+                        // An origin the lists were not built for: every sphere of the scene (the ray's first walk only).
+                        for (int i = 0; i < (seg == 0 ? s.ns_padded : 0); i++) {
                             float t;
                             if (grid_exact(s.sph[i], o, d, a, t)) {
                                 const int orig = s.sph_orig[i];
                                 if (t < best.lo || (t == best.lo && orig < best.prim)) best.lo = best.hi = t, best.prim = orig;
                             }
                         }
-                        tests += s.ns_padded;
+                        if (seg == 0) tests += s.ns_padded;
                     } else {
                         // The ray in cell coordinates and where it is inside the grid.
                         gx = (o.x - s.gr_lo[0]) * s.gr_ih[0], gy = (o.y - s.gr_lo[1]) * s.gr_ih[1], gz = (o.z - s.gr_lo[2]) * s.gr_ih[2];
@@ -2441,10 +2462,27 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
                         grid_slab(gy, ddy, ry, (float)n1, tny, tfy);
                         grid_slab(gz, ddz, rz, (float)n2, tnz, tfz);
                         const float t_in = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f)), t_out = fminf(fminf(tfx, tfy), tfz);
-                        if (t_in <= t_out && !(best.hi < t_in)) {   // the ray meets the grid before its closest hit so far
-                            const int ix = min(max((int)floorf(gx + t_in * ddx), 0), n0 - 1),
-                                      iy = min(max((int)floorf(gy + t_in * ddy), 0), n1 - 1),
-                                      iz = min(max((int)floorf(gz + t_in * ddz), 0), n2 - 1);
+                        bool walk = t_in <= t_out && !(best.hi < t_in);   // the ray meets the grid before its closest hit so far
+                        float t_from = t_in;
+                        seg_end = RT_FLT_MAX;
+                        if (segs > 1 && walk) {
+                            // This lane's part of the walk: segment `seg` of [t_in, where the ray leaves the grid or meets
+                            // its closest plane or triangle]; the last segment has no end of its own.
+                            const float t_to = fminf(t_out, best.hi), step = (t_to - t_in) * (1.0f / (float)segs);
+                            if (seg > 0) {
+                                // a hundredth of a cell early along the axis the ray crosses cells fastest on
+                                const float back = 0.01f * fminf(fminf(fabsf(rx), fabsf(ry)), fabsf(rz));
+                                t_from = fmaxf(t_in, (t_in + step * (float)seg) - back);
+                                // (not walked when a hit before this segment is known already; the plain read may miss
+                                // a minimum another wave is about to merge, which costs a walk, not the result)
+                                walk = !(__uint_as_float((unsigned)(G.key[my] >> 32)) < t_from) && step > 0.0f;
+                            }
+                            if (seg + 1 < segs) seg_end = t_in + step * (float)(seg + 1);
+                        }
+                        if (walk) {
+                            const int ix = min(max((int)floorf(gx + t_from * ddx), 0), n0 - 1),
+                                      iy = min(max((int)floorf(gy + t_from * ddy), 0), n1 - 1),
+                                      iz = min(max((int)floorf(gz + t_from * ddz), 0), n2 - 1);
                             cell = ix | (iy << 10) | (iz << 20);
                             // parameter at which the ray leaves the current cell along each axis
                             tmx = ddx == 0.0f ? RT_FLT_MAX : ((float)(ix + (rx > 0.0f ? 1 : 0)) - gx) * rx;
@@ -2503,7 +2541,7 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
                 tests += 2;
             }
             if (last) {
-                if (best.hi < leave || !inside || --left <= 0) {
+                if (best.hi < leave || !inside || --left <= 0 || leave >= seg_end) {
                     state = GRID_FINISHED;
                 } else {
                     cell = ncell;
@@ -2529,8 +2567,9 @@ __device__ __forceinline__ void reflection_tile_grid(const DevScene &s, const De
         const bool active = j < count;
         const int jj = active ? j : 0;
         const int slot = level * f.P + first + jj;
-        const int hit_prim = G.prim[jj];
-        const float t = G.t[jj];
+        const unsigned long long key = G.key[jj];
+        const int hit_prim = (int)(unsigned)key;
+        const float t = __uint_as_float((unsigned)(key >> 32));
         rd[k] = mk3(G.dx[jj], G.dy[jj], G.dz[jj]);
         f3 hit = mk3(0.f, 0.f, 0.f);
         if (active) {
@@ -2570,12 +2609,15 @@ k_reflect_grid(DevScene s, DevFrame f, int level)
     __shared__ int blk[12];
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int n = f.cnt[2 * level];
+    // Levels too small to fill the device: every ray's walk in segments, so many that the level comes to about
+    // grid_split_below walks (DevFrame), and tiles of 256 walks.
+    const int segs = n > 0 && n < f.grid_split_below ? max(1, min(GRID_SEGS_MAX, f.grid_split_below / n)) : 1;
     // Large levels: GRID_TILE_MAX records per tile (half as many contended counter atomics); small ones: 256, so
     // that more workgroups share the level.
-    const int per_tile = n >= GRID_TILE_MAX * (int)gridDim.x ? GRID_TILE_MAX : 256;
+    const int per_tile = segs > 1 ? 256 / segs : n >= GRID_TILE_MAX * (int)gridDim.x ? GRID_TILE_MAX : 256;
     TestCount tc = {0, 0, 0, 0, 0, 0, 0, 0};
     for (long long first = (long long)blockIdx.x * per_tile; first < n; first += (long long)gridDim.x * per_tile)
-        reflection_tile_grid<COUNT, false>(s, f, G, blk, level, (int)first, min(per_tile, n - (int)first), tc);
+        reflection_tile_grid<COUNT, false>(s, f, G, blk, level, (int)first, min(per_tile, n - (int)first), tc, segs);
     if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
 }
 
