@@ -162,11 +162,6 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
-    if os.environ.get("RT_BENCH_ONE_GPU"):
-        # Ranks that share one GPU (rehearsal only) keep every stream at the ordinary priority: on this pool a GPU
-        # that two processes share stalls when one of them waits on a stream of another priority
-        # (profiles/r02_two_rank_hang_evidence.txt).  One process per GPU, the real case, is not affected.
-        os.environ.setdefault("RT_HIP_AUX_PRIORITY", "0")
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("RT_BENCH_ONE_GPU") else local_rank
     # (before anything here touches the GPU: the child has the device to itself)

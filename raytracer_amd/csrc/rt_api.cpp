@@ -99,6 +99,10 @@ struct DeviceState {
     // second stream beside the reflecting records' (enqueue_rows), ordered by these events.
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_level[RT_MAX_DEPTH + 1] = {};
+    // The caller streams the second stream has been checked against (calibrate_second_stream: it shares a hardware
+    // queue with none of them), and the check's two words.
+    std::vector<hipStream_t> checked_against;
+    int *probe = nullptr;
 
     int num_cus = 256;
     // k_trace_levels workgroups resident at once, per instance [chain policy][counting] (0: ask
@@ -170,7 +174,9 @@ struct Tuning {
     int frame_parts = 0;         // RT_HIP_FRAME_PARTS: row blocks of rt_render's frame on one device
     int part_bands = -1;         // RT_HIP_PART_BANDS=0: contiguous row blocks instead of interleaved bands
     int host_gather = -1;        // RT_HIP_HOST_GATHER=0: several devices gather on the first one before the copy to the host
-    int aux_priority = -1;       // RT_HIP_AUX_PRIORITY=0 (read by rt_create): the second stream at the ordinary priority
+    int aux_priority = -1;       // RT_HIP_AUX_PRIORITY=1 (read by rt_create): the second stream at the lowest priority (experiment)
+    int calibrate = -1;          // RT_HIP_CALIBRATE_STREAMS=0: take the second stream as it comes
+    long long frame_timeout_ms = 0;   // RT_HIP_FRAME_TIMEOUT_MS: how long rt_render / rt_frame_status wait for the device (default 30000)
     int mover_threads = -1;      // RT_HIP_MOVER_THREADS: helper threads of a staged frame's host-side move (0: the caller alone)
     bool handoff_trace = false;  // RT_HIP_HANDOFF_TRACE (set before the first frame): rt_render prints, per row block, when the
                                  // host enqueued it and when the device finished its kernels and its copy
@@ -207,6 +213,8 @@ Tuning read_tuning()
     t.part_bands = (int)num("RT_HIP_PART_BANDS", -1);
     t.host_gather = (int)num("RT_HIP_HOST_GATHER", -1);
     t.aux_priority = (int)num("RT_HIP_AUX_PRIORITY", -1);
+    t.calibrate = (int)num("RT_HIP_CALIBRATE_STREAMS", -1);
+    t.frame_timeout_ms = num("RT_HIP_FRAME_TIMEOUT_MS", 0);
     t.mover_threads = (int)num("RT_HIP_MOVER_THREADS", -1);
     t.handoff_trace = getenv("RT_HIP_HANDOFF_TRACE") != nullptr;
     return t;
@@ -228,6 +236,7 @@ struct rt_ctx {
     std::vector<DeviceState> dev;
     char error[RT_ERROR_CHARS] = "";
     bool have_scene = false;
+    bool wedged = false;           // a device did not come back within the time limit: nothing of this context may wait for it again
     int profiling = 0;             // RT_PROFILE_*: 0 off, 1 counters and event timing, 2 event timing only
     int share = 1;                 // contexts rendering on this context's devices at the same time (rt_set_device_share)
     Tuning tune;
@@ -1432,12 +1441,10 @@ hipError_t scratch_address(int device, unsigned char **out)
 
 
 // Streams, events, the status block and the fixed scratch's address of one device state (the device is current).
-// aux_low_priority: the second stream is created at the lowest stream priority.  Not for the priority's sake (the
-// plain records' launches may well yield to the chain's) but for the hardware queue: the runtime maps every stream
-// of a process onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), by priority class, and two streams
-// that share a queue run one after the other.  A caller's stream that lands on the second stream's queue costs
-// the frame its overlap of chain and plain launches - the 64k-sphere scene 3.71 instead of 2.61 ms in a process
-// whose fourth stream carried the frames - and a stream of another priority class can share no queue with it.
+// aux_low_priority (RT_HIP_AUX_PRIORITY=1, an experiment): the second stream at the lowest stream priority, i.e. in a
+// priority class, and therefore on a hardware queue, no ordinary stream shares.  Not the default: on the pool this
+// library was measured on a frame's launches on such a stream now and then never start (the test-suite stalls in
+// one of its ~100 frames), like the high-priority copy stream that stalls two processes sharing a GPU.
 hipError_t create_device_objects(DeviceState &d, bool aux_low_priority)
 {
     hipError_t e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
@@ -1457,6 +1464,7 @@ hipError_t create_device_objects(DeviceState &d, bool aux_low_priority)
     if (e == hipSuccess) e = hipHostMalloc((void **)&d.status, 64, hipHostMallocMapped);
     if (e == hipSuccess) memset(d.status, 0, 64);
     if (e == hipSuccess) e = scratch_address(d.device, &d.scratch_base);
+    if (e == hipSuccess) e = hipMalloc((void **)&d.probe, 64);
     return e;
 }
 
@@ -1480,6 +1488,7 @@ void destroy_device_state(DeviceState &d)
     if (d.stream) (void)hipStreamDestroy(d.stream);
     if (d.status) (void)hipHostFree(d.status);
     if (d.bands) (void)hipFree(d.bands);
+    if (d.probe) (void)hipFree(d.probe);
 }
 
 // Bytes of the fixed scratch array a frame of P pixels and max_depth + 1 levels needs: the control
@@ -1562,6 +1571,7 @@ int ensure_frame(rt_ctx *ctx, DeviceState &d, int P, int max_depth)
 int check_render_args(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_depth)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
+    if (ctx->wedged) return fail(ctx, RT_ERR_STALLED, "a device of this context did not come back from an earlier frame; destroy the context");
     if (!cam) return fail(ctx, RT_ERR_INVALID_ARG, "camera is NULL");
     if (w <= 0 || h <= 0) return fail(ctx, RT_ERR_INVALID_ARG, "bad frame size %d x %d", w, h);
     if (max_depth < 0 || max_depth > RT_MAX_DEPTH)
@@ -1574,6 +1584,50 @@ int check_render_args(rt_ctx *ctx, const rt_camera *cam, int w, int h, int max_d
         return fail(ctx, RT_ERR_BAD_TEXTURE, "a primitive uses texture slot %d, which is not loaded", slot);
     }
     return RT_OK;
+}
+
+// Waiting for the device with a deadline: a frame that does not come back within RT_HIP_FRAME_TIMEOUT_MS (default
+// 30 s; a frame takes milliseconds) is reported as RT_ERR_STALLED, with what the device had reached, instead of
+// holding the caller for ever.  (The wait polls: spinning at first, then in steps of 50 us.)
+hipError_t wait_until(rt_ctx *ctx, const std::function<hipError_t()> &query)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const long long limit_ms = ctx->tune.frame_timeout_ms > 0 ? ctx->tune.frame_timeout_ms : 30000;
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t e = query();
+        if (e != hipErrorNotReady) return e;
+        if (spins < 4096) continue;
+        const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (waited >= limit_ms) {
+            (void)hipGetLastError();
+            return hipErrorNotReady;
+        }
+        if (waited >= 2) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
+// What a frame that did not come back had reached on device state d (for the error message).
+void describe_progress(DeviceState &d, char *out, size_t n)
+{
+    int reached = -1;
+    for (int k = 0; k <= d.last_depth && k <= RT_MAX_DEPTH; k++)
+        if (d.ev_level[k] && hipEventQuery(d.ev_level[k]) == hipSuccess) reached = k;
+    const bool aux_done = !d.aux || hipStreamQuery(d.aux) == hipSuccess;
+    (void)hipGetLastError();
+    snprintf(out, n, "device %d: %d pixels, max_depth %d; the chain's launches are done up to level %d, the second stream is %s",
+             d.device, d.last_P, d.last_depth, reached, aux_done ? "idle" : "still busy");
+}
+
+int wait_stream(rt_ctx *ctx, DeviceState &d, hipStream_t stream)
+{
+    const hipError_t e = wait_until(ctx, [&] { return hipStreamQuery(stream); });
+    if (e == hipSuccess) return RT_OK;
+    if (e != hipErrorNotReady) return fail(ctx, RT_ERR_HIP, "waiting for device %d failed: %s", d.device, hipGetErrorString(e));
+    char what[256];
+    describe_progress(d, what, sizeof what);
+    ctx->wedged = true;
+    return fail(ctx, RT_ERR_STALLED, "the frame did not come back within the time limit (RT_HIP_FRAME_TIMEOUT_MS); %s; the context "
+                "must be destroyed", what);
 }
 
 // After the device has finished the frames enqueued so far (the caller has synchronised the
@@ -1626,6 +1680,61 @@ int check_schedule(rt_ctx *ctx, DeviceState &d)
 // call.part < 0: the call is a frame of its own.  call.part >= 0: that part of a frame rendered in parts:
 // its outcome is copied to d.outcome_snap behind its kernels.
 // call.fixed_scratch: the frame's queues live in the library's fixed scratch array and nothing is allocated.
+// Do launches on `a` run beside launches on `x`, or does the runtime keep both streams on one hardware queue (it
+// maps a process's streams onto GPU_MAX_HW_QUEUES queues, 4 by default, least used first; launches of one queue
+// are serial)?  A waiter on x, a setter on a behind it (rt_kernels.hip, k_probe_wait).  Synchronises both streams.
+int streams_overlap(rt_ctx *ctx, DeviceState &d, hipStream_t x, hipStream_t a, bool *overlap)
+{
+    *overlap = true;
+    int seen = 0;
+    for (int attempt = 0; attempt < 2 && !seen; attempt++) {   // (once more before a "no": a setter may just have been late)
+        HIP_TRY(ctx, hipMemsetAsync(d.probe, 0, 8, x));
+        HIP_TRY(ctx, hipEventRecord(d.ev_fork, x));
+        rtk_probe_wait(d.probe, 30000ull << attempt, x);   // 300 us, then 600
+        HIP_TRY(ctx, hipStreamWaitEvent(a, d.ev_fork, 0));
+        rtk_probe_set(d.probe, a);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(x));
+        HIP_TRY(ctx, hipStreamSynchronize(a));
+        int words[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpy(words, d.probe, sizeof words, hipMemcpyDeviceToHost));
+        seen = words[1];
+    }
+    *overlap = seen != 0;
+    return RT_OK;
+}
+
+// The frame's two streams must not share a hardware queue: the chain of reflection levels and the plain records'
+// launches would run one after the other (the 64k-sphere scene 3.71 instead of 2.61 ms per frame in a process
+// whose fourth stream carried the frames).  Checked once per caller stream; a second stream that does share the
+// caller's queue is replaced by a new one (the runtime gives a new stream the least used queue) until one does
+// not, a few times at most.  Costs about a millisecond, the first time a stream is seen.
+int calibrate_second_stream(rt_ctx *ctx, DeviceState &d, hipStream_t stream)
+{
+    // (a host that alternates between a few streams keeps all of them on the list; more than a hardware has queues
+    // cannot all be avoided: the oldest goes)
+    if (d.checked_against.size() >= 3) d.checked_against.erase(d.checked_against.begin());
+    d.checked_against.push_back(stream);
+    std::vector<hipStream_t> rejected;
+    int rc = RT_OK;
+    for (int tries = 0; tries < 6; tries++) {
+        bool overlap = true;
+        // the stream just added first: the others passed with the second stream as it is
+        for (size_t k = d.checked_against.size(); k-- > 0 && overlap;)
+            if ((rc = streams_overlap(ctx, d, d.checked_against[k], d.aux, &overlap)) != RT_OK) break;
+        if (rc != RT_OK || overlap) break;
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        rejected.push_back(d.aux);   // (kept until a good one is found, so that the next one gets another queue)
+        d.aux = fresh;
+    }
+    for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
+    return rc;
+}
+
 struct RowsCall {
     int part = -1;
     bool keep_counters = false;   // the work counters run on from the parts this device state rendered before
@@ -1837,6 +1946,10 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
         // The chain stays on the caller's stream (a dependency between two launches of one stream costs
         // ~6 us, across streams ~12, and the chain is the frame's critical path); the plain records'
         // launches go to the second stream, except the deepest level's, which the chain ends with.
+        if (two_streams && !fixed_scratch && tune.calibrate != 0 &&
+            std::find(d.checked_against.begin(), d.checked_against.end(), stream) == d.checked_against.end() &&
+            (rc = calibrate_second_stream(ctx, d, stream)) != RT_OK)
+            return rc;
         hipStream_t side = two_streams ? d.aux : stream;
         if (two_streams) {
             HIP_TRY(ctx, hipEventRecord(d.ev_fork, stream));
@@ -1937,7 +2050,7 @@ int rt_create(rt_ctx **out, const int *device_ids, int n_devices)
             rt_destroy(ctx);
             return rc;
         }
-        if (e == hipSuccess) e = create_device_objects(d, ctx->tune.aux_priority != 0);
+        if (e == hipSuccess) e = create_device_objects(d, ctx->tune.aux_priority > 0);
         if (e != hipSuccess) {
             int rc = fail(nullptr, RT_ERR_HIP, "device %d setup failed: %s", d.device, hipGetErrorString(e));
             rt_destroy(ctx);
@@ -1973,6 +2086,13 @@ int rt_create(rt_ctx **out, const int *device_ids, int n_devices)
 void rt_destroy(rt_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->wedged) {
+        // A device that stopped answering would hold every synchronising call for ever (hipFree included): the
+        // context's device memory and streams are abandoned, only the host side goes.
+        delete ctx->movers;
+        delete ctx;
+        return;
+    }
     for (DeviceState &d : ctx->dev) destroy_device_state(d);
     if (ctx->staging) (void)hipHostFree(ctx->staging);
     if (!ctx->dev.empty()) (void)hipSetDevice(ctx->dev[0].device);
@@ -2227,7 +2347,8 @@ static int render_to_host(rt_ctx *ctx, const rt_camera *cam, int w, int h, int m
         auto work = [&](int worker, int workers) {
             if (worker > 0) (void)hipSetDevice(device);
             for (size_t k = (size_t)worker; k < pieces.size(); k += (size_t)workers) {
-                const hipError_t e = hipEventSynchronize(ctx->copy_ev[k]);
+                hipEvent_t ev = ctx->copy_ev[k];
+                const hipError_t e = wait_until(ctx, [ev] { return hipEventQuery(ev); });
                 if (e != hipSuccess) {
                     failed.store((int)e);
                     break;
@@ -2241,6 +2362,13 @@ static int render_to_host(rt_ctx *ctx, const rt_camera *cam, int w, int h, int m
         };
         if (helpers > 0) ctx->movers->run(work);
         else work(0, 1);
+        if ((hipError_t)failed.load() == hipErrorNotReady) {
+            char what[256];
+            describe_progress(root, what, sizeof what);
+            ctx->wedged = true;
+            return fail(ctx, RT_ERR_STALLED, "the frame's pixels did not arrive within the time limit (RT_HIP_FRAME_TIMEOUT_MS); %s; "
+                        "the context must be destroyed", what);
+        }
         HIP_TRY(ctx, (hipError_t)failed.load());
         return RT_OK;
     };
@@ -2317,7 +2445,7 @@ static int render_to_host(rt_ctx *ctx, const rt_camera *cam, int w, int h, int m
             first_piece[p + 1] = pieces.size();
         }
         if ((rc = drain_copy()) != RT_OK) return rc;
-        HIP_TRY(ctx, hipStreamSynchronize(root.stream));   // (done already: the copies waited for the kernels)
+        if ((rc = wait_stream(ctx, root, root.stream)) != RT_OK) return rc;   // (done already: the copies waited for the kernels)
         ctx->gather_ms = 0.0;
         // Here the copy overlaps the kernels: what is reported is the time of the whole call.
         ctx->copy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
@@ -2442,7 +2570,7 @@ static int render_to_host(rt_ctx *ctx, const rt_camera *cam, int w, int h, int m
     for (int g = G - 1; g >= 0; g--) {
         DeviceState &d = ctx->dev[g];
         HIP_TRY(ctx, hipSetDevice(d.device));
-        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+        if ((rc = wait_stream(ctx, d, d.stream)) != RT_OK) return rc;
         if ((g > 0 || interleaved || host_gather) && d.timed && d.last_P > 0) {
             float ms = 0.f;   // (host gather: the device's own copy to the host)
             if (hipEventElapsedTime(&ms, d.ev[3], d.ev[4]) == hipSuccess)
@@ -2477,8 +2605,8 @@ int rt_frame_status(rt_ctx *ctx)
         for (DeviceState &d : ctx->dev) {
             if (!d.last_stream) continue;
             HIP_TRY(ctx, hipSetDevice(d.device));
-            HIP_TRY(ctx, hipStreamSynchronize(d.last_stream));
-            const int r = check_schedule(ctx, d);
+            int r = wait_stream(ctx, d, d.last_stream);
+            if (r == RT_OK) r = check_schedule(ctx, d);
             if (r != RT_OK) rc = r;
         }
         return rc;

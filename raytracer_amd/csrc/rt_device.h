@@ -278,5 +278,9 @@ void rtk_shade_lights(const DevScene &s, const DevFrame &f, int level, int queue
 // Raytracer.Debug's rays: 16 floats per ray (rt_debug_ray's 14 words, then two of padding).
 void rtk_debug_rays(const DevScene &s, const DevCamera &cam, int row, int x_step, int count, float *out,
                     hipStream_t stream);
+// The two launches of the test whether two streams share a hardware queue (rt_api.cpp, streams_overlap): words[0]
+// = the flag (zero before), words[1] = what the waiter saw.
+void rtk_probe_wait(int *words, unsigned long long ticks, hipStream_t stream);
+void rtk_probe_set(int *words, hipStream_t stream);
 // The present path's FXAA filter over a w x h frame (in and out must not overlap).
 void rtk_fxaa(const int32_t *in, int32_t *out, int w, int h, hipStream_t stream);

@@ -3279,6 +3279,28 @@ void rtk_debug_rays(const DevScene &s, const DevCamera &cam, int row, int x_step
     hipLaunchKernelGGL(k_debug_rays, dim3((count + 63) / 64), dim3(64), 0, stream, s, cam, row, x_step, count, out);
 }
 
+// Do two streams share a hardware queue?  k_probe_wait waits (one lane, at most `ticks` of the 100 MHz wall clock)
+// for the word k_probe_set writes, and reports whether it saw it: launches of one hardware queue run one after
+// the other, so a setter enqueued behind the waiter on the same queue comes too late.
+__global__ void k_probe_wait(int *words, unsigned long long ticks)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    int seen = 0;
+    while ((seen = __hip_atomic_load(&words[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && wall_clock64() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(16);
+    words[1] = seen;
+}
+__global__ void k_probe_set(int *words)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(&words[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+void rtk_probe_wait(int *words, unsigned long long ticks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, stream, words, ticks);
+}
+void rtk_probe_set(int *words, hipStream_t stream) { hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(64), 0, stream, words); }
+
 void rtk_fxaa(const int32_t *in, int32_t *out, int w, int h, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_fxaa, dim3((w + 31) / 32, (h + 7) / 8), dim3(256), 0, stream, in, out, w, h);

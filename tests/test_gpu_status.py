@@ -41,3 +41,24 @@ def test_stalled_schedule_surfaces_through_every_entry(oracle, monkeypatch):
         c.frame_status()
         assert np.array_equal(buf.cpu().numpy(), ref)
         assert np.array_equal(c.render(cam, w, h, depth), ref)
+
+
+def test_frames_on_many_caller_streams_are_the_same_frame(oracle):
+    """A host may hand over any stream, and a new one every frame.  The runtime keeps a process's streams on a
+    few hardware queues, so sooner or later a caller's stream shares one with the context's second stream; the
+    library checks the pair the first time it sees a stream and takes another second stream if need be (a
+    hazard for the frame's time, never for its pixels).  Eight streams, two scenes: every frame is the frame."""
+    import torch
+    fs, cam, (w, h), depth = scene_1k().flatten(), Camera(), (320, 200), 3
+    ref, _ = oracle.render(fs, cam, w, h, max_depth=depth)
+    buf = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    with RenderContext() as c:
+        c.set_scene(fs)
+        for rounds in range(2):
+            for s in streams:
+                buf.zero_()
+                torch.cuda.synchronize()
+                c.render_rows_device(cam, w, h, 0, h, depth, buf.data_ptr(), s.cuda_stream)
+                c.frame_status()
+                assert np.array_equal(buf.cpu().numpy(), ref)
