@@ -99,9 +99,11 @@ struct DeviceState {
     // second stream beside the reflecting records' (enqueue_rows), ordered by these events.
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_level[RT_MAX_DEPTH + 1] = {};
-    // The caller streams the second stream has been checked against (calibrate_second_stream: it shares a hardware
-    // queue with none of them), and the check's two words.
+    // The caller streams the second stream, as it is now, has been checked against (calibrate_second_stream: it
+    // shares a hardware queue with none of them).  Handles only, never used again: a caller may have destroyed its
+    // stream since.  replaced: how often the second stream was exchanged (bounded).  probe: the check's two words.
     std::vector<hipStream_t> checked_against;
+    int replaced = 0;
     int *probe = nullptr;
 
     int num_cus = 256;
@@ -1711,18 +1713,15 @@ int streams_overlap(rt_ctx *ctx, DeviceState &d, hipStream_t x, hipStream_t a, b
 // not, a few times at most.  Costs about a millisecond, the first time a stream is seen.
 int calibrate_second_stream(rt_ctx *ctx, DeviceState &d, hipStream_t stream)
 {
-    // (a host that alternates between a few streams keeps all of them on the list; more than a hardware has queues
-    // cannot all be avoided: the oldest goes)
-    if (d.checked_against.size() >= 3) d.checked_against.erase(d.checked_against.begin());
-    d.checked_against.push_back(stream);
+    // Only `stream`, which the caller vouches for in this call, is ever launched on: streams seen in earlier calls
+    // may be gone.  A host that alternates between streams gets each checked when it comes; should they keep
+    // displacing one another's second stream (more caller streams than the runtime has queues to spare), the
+    // exchanges stop after a few and the streams are taken as they are.
     std::vector<hipStream_t> rejected;
     int rc = RT_OK;
-    for (int tries = 0; tries < 6; tries++) {
+    for (int tries = 0; tries < 6 && d.replaced < 12; tries++) {
         bool overlap = true;
-        // the stream just added first: the others passed with the second stream as it is
-        for (size_t k = d.checked_against.size(); k-- > 0 && overlap;)
-            if ((rc = streams_overlap(ctx, d, d.checked_against[k], d.aux, &overlap)) != RT_OK) break;
-        if (rc != RT_OK || overlap) break;
+        if ((rc = streams_overlap(ctx, d, stream, d.aux, &overlap)) != RT_OK || overlap) break;
         hipStream_t fresh = nullptr;
         if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError();
@@ -1730,8 +1729,12 @@ int calibrate_second_stream(rt_ctx *ctx, DeviceState &d, hipStream_t stream)
         }
         rejected.push_back(d.aux);   // (kept until a good one is found, so that the next one gets another queue)
         d.aux = fresh;
+        d.replaced++;
+        d.checked_against.clear();   // (what passed with the old second stream must be looked at again when it comes)
     }
     for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
+    if (d.checked_against.size() >= 8) d.checked_against.erase(d.checked_against.begin());
+    d.checked_against.push_back(stream);
     return rc;
 }
 
