@@ -384,7 +384,7 @@ int rt_debug_rays(rt_ctx *ctx, const rt_camera *camera, int width, int height, i
  * devices (needed to read the device-side counters). */
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 
-/* Reads the library's tuning aids and test knobs (environment variables RT_HIP_*: README, "Tuning aids") again;
+/* Reads the library's tuning aids and test knobs (environment variables RT_HIP_*: INTEGRATION.md, "Environment variables") again;
  * rt_create and rt_set_scene do the same.  No frame reads the environment.  No counterpart in the reference. */
 int rt_reload_tuning(rt_ctx *ctx);
 
