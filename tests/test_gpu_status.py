@@ -62,3 +62,35 @@ def test_frames_on_many_caller_streams_are_the_same_frame(oracle):
                 c.render_rows_device(cam, w, h, 0, h, depth, buf.data_ptr(), s.cuda_stream)
                 c.frame_status()
                 assert np.array_equal(buf.cpu().numpy(), ref)
+
+
+def test_host_side_deadline_reports_where_the_device_was(oracle, monkeypatch):
+    """No wait on the device is unbounded: with a deadline shorter than the frame (the frame is made long by the knob
+    that stalls the single-launch form's schedule for 400 ms) rt_render comes back with RT_ERR_STALLED and a
+    description of what the device had reached; the context then refuses further frames and is destroyed without
+    waiting for the device; a new context renders the frame."""
+    import time
+    fs, cam, (w, h), depth = scene_1k().flatten(), Camera(), (320, 200), 3
+    ref, _ = oracle.render(fs, cam, w, h, max_depth=depth)
+    monkeypatch.setenv("RT_HIP_PIPELINE", "fused")
+    monkeypatch.setenv("RT_HIP_STALL_MS", "400")
+    monkeypatch.setenv("RT_HIP_DEBUG_WITHHOLD_LEVEL", "0")
+    monkeypatch.setenv("RT_HIP_FRAME_TIMEOUT_MS", "50")
+    c = RenderContext()
+    c.set_scene(fs)
+    t = time.perf_counter()
+    with pytest.raises(RtError) as e:
+        c.render(cam, w, h, depth)
+    waited = time.perf_counter() - t
+    assert e.value.status == -8 and "time limit" in e.value.message and "second stream" in e.value.message
+    assert 0.04 < waited < 0.35
+    with pytest.raises(RtError) as e:
+        c.render(cam, w, h, depth)
+    assert e.value.status == -8 and "destroy the context" in e.value.message
+    c.close()
+    time.sleep(0.6)                        # (the abandoned launch gives up by itself after its own limit)
+    for k in ("RT_HIP_PIPELINE", "RT_HIP_STALL_MS", "RT_HIP_DEBUG_WITHHOLD_LEVEL", "RT_HIP_FRAME_TIMEOUT_MS"):
+        monkeypatch.delenv(k)
+    with RenderContext() as c2:
+        c2.set_scene(fs)
+        assert np.array_equal(c2.render(cam, w, h, depth), ref)
