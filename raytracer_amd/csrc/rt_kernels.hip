@@ -2799,19 +2799,33 @@ k_plain_tail(DevScene s, DevFrame f, int level, int level_hi, int32_t *pixels)
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     TestCount tc = {0, 0, 0, 0, 0, 0, 0};
     PhaseClock pc = {};
+    // The tiles of all the queues as ONE list of jobs - level by level, the plain queue and then the reflecting
+    // queue's light terms -, so that a workgroup's turns are spread over the queues instead of every workgroup
+    // working through one tile of each queue in a row (four chains of dependent reads one after the other: the
+    // launch took 37 us for half a million records of the 3840x2160 frame's levels 2 and 3).
+    int total = 0;
     for (int lv = level; lv <= level_hi; lv++) {
-        const int n = f.cnt[2 * lv + 1];
-        if (!(f.light_waves > 0 && n < f.light_split_below)) {   // (else k_shade_lights takes this queue)
-            const int ntiles = (n + 255) >> 8;
-            for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) plain_tile<COUNT>(s, f, lv, tile, n, pixels, tc, pc);
-        }
-        if (lv < f.max_depth && lit_ahead(f, f.cnt[2 * lv]) && !(f.light_waves > 0 && f.cnt[2 * lv] < f.light_split_below)) {
-            const int na = f.cnt[2 * lv];
-            const int ntiles = (na + 255) >> 8;
-            for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int nb = f.cnt[2 * lv + 1], na = f.cnt[2 * lv];
+        if (!(f.light_waves > 0 && nb < f.light_split_below)) total += (nb + 255) >> 8;   // (else k_shade_lights takes this queue)
+        if (lv < f.max_depth && lit_ahead(f, na) && !(f.light_waves > 0 && na < f.light_split_below)) total += (na + 255) >> 8;
+    }
+    for (int job = blockIdx.x; job < total; job += gridDim.x) {
+        int tile = job;
+        for (int lv = level; lv <= level_hi; lv++) {
+            const int nb = f.cnt[2 * lv + 1], na = f.cnt[2 * lv];
+            const int tiles_b = !(f.light_waves > 0 && nb < f.light_split_below) ? (nb + 255) >> 8 : 0;
+            if (tile < tiles_b) {
+                plain_tile<COUNT>(s, f, lv, tile, nb, pixels, tc, pc);
+                break;
+            }
+            tile -= tiles_b;
+            const int tiles_a = lv < f.max_depth && lit_ahead(f, na) && !(f.light_waves > 0 && na < f.light_split_below) ? (na + 255) >> 8 : 0;
+            if (tile < tiles_a) {
                 const int i = tile * 256 + threadIdx.x;
                 lit_record<COUNT>(s, f, lv, lv * f.P + (i < na ? i : na - 1), i < na, tc);
+                break;
             }
+            tile -= tiles_a;
         }
     }
     if constexpr (COUNT) flush_test_counts(f, cnt_sh, tc);
