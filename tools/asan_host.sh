@@ -31,7 +31,8 @@ sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 from raytracer_amd import Camera, RenderContext, default_scene, scene_1k, scene_64k
 from test_abi_consumer import write_scene
 out = sys.argv[1]
-for name, scene, w, h, depth in (("default", default_scene, 96, 96, 5), ("1k", scene_1k, 320, 180, 4), ("64k", scene_64k, 192, 108, 8)):
+for name, scene, w, h, depth in (("default", default_scene, 96, 96, 5), ("1k", scene_1k, 320, 180, 4), ("64k", scene_64k, 192, 108, 8),
+                                 ("1k_blocks", scene_1k, 2048, 1609, 3)):   # (3.3 M pixels: row blocks, strided copies, helper threads)
     fs = scene().flatten()
     with RenderContext([0]) as c:
         c.set_scene(fs)
@@ -40,7 +41,7 @@ for name, scene, w, h, depth in (("default", default_scene, 96, 96, 5), ("1k", s
     frame.astype(np.int32).tofile(os.path.join(out, name + ".raw"))
     print(name, w, h, depth)
 PY
-    for cfg in "default 96 96 5" "1k 320 180 4" "64k 192 108 8"; do
+    for cfg in "default 96 96 5" "1k 320 180 4" "64k 192 108 8" "1k_blocks 2048 1609 3"; do
         set -- $cfg
         echo "== $1"
         ASAN_OPTIONS=detect_leaks=0:abort_on_error=0 timeout -k 10 300 "$V/abi_consumer_asan" "$W/$1.bin" "$2" "$3" "$4" "$W/$1.raw"
