@@ -171,6 +171,8 @@ struct Tuning {
     int early_lights = -1;       // RT_HIP_EARLY_LIGHTS=0 turns the light terms ahead of the children off
     int early_lights_max = 16;   // RT_HIP_EARLY_LIGHTS_MAX: the most lights it is used for
     int early_lights_below = -1; // RT_HIP_EARLY_LIGHTS_BELOW: the bound in records (0: every level)
+    int path_shade = -1;         // RT_HIP_PATH_SHADE=0: one k_shade launch per level even when one launch could sum the paths;
+                                 // n > 0: the paths' launch takes the levels from n - 1 down
     int reflect_blocks = 8, plain_blocks = 16, light_blocks = 8;   // RT_HIP_REFLECT_BLOCKS / _PLAIN_BLOCKS / _LIGHT_BLOCKS: workgroups per compute unit
     size_t copy_chunk_pixels = 0;   // RT_HIP_COPY_CHUNK_KIB
     int frame_parts = 0;         // RT_HIP_FRAME_PARTS: row blocks of rt_render's frame on one device
@@ -206,6 +208,7 @@ Tuning read_tuning()
     t.early_lights = (int)num("RT_HIP_EARLY_LIGHTS", -1);
     t.early_lights_max = (int)num("RT_HIP_EARLY_LIGHTS_MAX", 16);
     t.early_lights_below = (int)num("RT_HIP_EARLY_LIGHTS_BELOW", -1);
+    t.path_shade = (int)num("RT_HIP_PATH_SHADE", -1);
     auto positive = [&](const char *name, int dflt) { const long long v = num(name, 0); return v > 0 ? (int)v : dflt; };
     t.reflect_blocks = positive("RT_HIP_REFLECT_BLOCKS", 8);
     t.plain_blocks = positive("RT_HIP_PLAIN_BLOCKS", 16);
@@ -1915,6 +1918,11 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
             if (want <= d.cap_lit) fr.lit = d.lit;
         }
     }
+    // The sums of the reflecting records path by path in one launch (k_shade_paths) when every level's light terms
+    // are there; the levels above path_lo keep their own launches.
+    const int path_lo = tune.path_shade > 0 ? std::min(tune.path_shade - 1, std::max(0, max_depth - 2)) : 0;
+    fr.path_shade = fr.lit && fr.lit_below <= 0 && fr.bin_min <= 0 && !fused && max_depth >= 2 &&
+                    tune.path_shade != 0;
     d.last_stream = stream;
     const DevFrame &f = fr;
     if (call.keep_counters) HIP_TRY(ctx, hipMemsetAsync(f.sched, 0, FRAME_CONTROL_BYTES - RT_COUNTER_SLOTS * sizeof(DevCounters), stream));
@@ -1997,7 +2005,8 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // (measured at 3840x2160: 0.128 ms against 0.145 with 8 and 0.143 with 128).
     const int shade_blocks = std::max(1, std::min((P + 255) / 256, d.num_cus * 32));
     // (the reflecting records; the deepest level has none)
-    for (int k = max_depth - 1; k >= 0; k--) {
+    if (f.path_shade) rtk_shade_paths(d.scene, f, path_lo, dev_pixels, std::min(shade_blocks, RT_COUNTER_SLOTS), stream);
+    for (int k = (f.path_shade ? path_lo : max_depth) - 1; k >= 0; k--) {
         rtk_shade_level(d.scene, f, k, dev_pixels, std::min(shade_blocks, RT_COUNTER_SLOTS), stream);
         if (f.light_waves && (!f.lit || f.lit_below > 0))
             rtk_shade_lights(d.scene, f, k, 1, dev_pixels, std::max(1, std::min(d.num_cus * 8 / share, RT_COUNTER_SLOTS)), stream);

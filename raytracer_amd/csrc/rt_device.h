@@ -235,6 +235,8 @@ struct DevFrame {
     int lit_stride;        // records per level that lit has room for
     int lit_below;         // > 0: only for levels of fewer than that many reflecting records (the others run their
                            // whole light loop once their children are shaded)
+    int path_shade;        // 1: a reflecting record whose child reflects too is marked (refl.w = RT_REFL_PENDING), and the
+                           // sums of the levels from path_lo down run path by path in one launch (k_shade_paths)
     int light_waves;       // > 0: queues of fewer than light_split_below records are shaded with the lights spread
     int light_split_below; // over that many waves per 64 records (k_shade_lights)
     int spread_below;      // one-chunk scenes: levels with fewer reflecting tiles than this take 64 records per workgroup
@@ -264,6 +266,9 @@ int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus, bool reserv
 void rtk_trace_levels(const DevScene &s, const DevFrame &f, int32_t *pixels, int grid_blocks, hipStream_t stream);
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
                      int grid_blocks, hipStream_t stream);
+// The sums of the reflecting records of every level from level_lo down, path by path (needs DevFrame::path_shade
+// and the light terms of all those levels in DevFrame::lit).
+void rtk_shade_paths(const DevScene &s, const DevFrame &f, int level_lo, int32_t *pixels, int grid_blocks, hipStream_t stream);
 // The plain records of levels level_lo .. level_hi in one launch, with the light terms of their reflecting
 // records when DevFrame::lit is set.
 void rtk_plain_levels(const DevScene &s, const DevFrame &f, int level_lo, int level_hi, int32_t *pixels, int grid_blocks,

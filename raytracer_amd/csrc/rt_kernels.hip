@@ -228,6 +228,10 @@ __device__ __forceinline__ void load_record(const float4 *a, const float4 *b, fl
     rb = make_float4(vb.x, vb.y, vb.z, vb.w);
 }
 
+// refl[slot].w of a reflecting record: 0 = its ray met nothing, 1 = xyz is the child's colour, and (frames with
+// DevFrame::path_shade) RT_REFL_PENDING = the child reflects too and has not been summed yet.
+#define RT_REFL_PENDING 2.0f
+
 // Append up to N new hit records per thread to level `level`, with ONE atomic per queue per
 // WORKGROUP: a single counter word takes only ~90 returning atomics per microsecond, and a
 // frame appends hundreds of thousands of waves' worth of records.  Every thread of the
@@ -293,6 +297,13 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
             } else {
                 f.recA[slot] = make_float4(hit[k].x, hit[k].y, hit[k].z, __int_as_float(prim[k]));
                 f.recB[slot] = make_float4(view[k].x, view[k].y, view[k].z, __int_as_float(parent[k]));
+            }
+            // The parent of a record that reflects in its turn is told so (k_shade_paths): after the parent's own
+            // "no reflected colour yet", which this lane stored before the call.
+            if (f.path_shade && level >= 1 && is_a[k]) {
+                uint32_t *w = reinterpret_cast<uint32_t *>(&f.refl[parent[k]]) + 3;
+                if (THROUGH) store_word_through(w, __float_as_uint(RT_REFL_PENDING));
+                else *w = __float_as_uint(RT_REFL_PENDING);
             }
             // Frames whose reflection rays are traced chunk by chunk (k_reflect_chunks) keep the
             // closest hit so far in the first two words of the record's refl slot: nothing yet.
@@ -1855,12 +1866,13 @@ __device__ __forceinline__ void lit_record(const DevScene &s, const DevFrame &f,
     }
 }
 
-__device__ __forceinline__ void combine_record(const DevScene &s, const DevFrame &f, const int level, const int slot,
-                                               int32_t *pixels)
+// rf: the record's refl entry (the child's colour, w != 0 when there is one).
+__device__ __forceinline__ f3 combine_sum(const DevScene &s, const DevFrame &f, const int level, const int slot,
+                                          const float4 rf, int &parent)
 {
-    const int prim = __float_as_int(f.recA[slot].w), parent = __float_as_int(f.recB[slot].w);
+    const int prim = __float_as_int(f.recA[slot].w);
+    parent = __float_as_int(f.recB[slot].w);
     const float specular = cload(s.mat, 3 * prim).w;
-    const float4 rf = f.refl[slot];
     const bool have_refl = rf.w != 0.0f;
     const f3 refl_term = scale3(scale3(xyz(rf), specular), 1.0f);   // (Vector4)Shade(..) * material.specular * 1
     f3 final = mk3(0.0f, 0.0f, 0.0f);
@@ -1870,6 +1882,14 @@ __device__ __forceinline__ void combine_record(const DevScene &s, const DevFrame
         if (have_refl) final = add3(final, mk3(ieee_div(refl_term.x, t.w), ieee_div(refl_term.y, t.w), ieee_div(refl_term.z, t.w)));
         final = add3(final, xyz(t));
     }
+    return final;
+}
+
+__device__ __forceinline__ void combine_record(const DevScene &s, const DevFrame &f, const int level, const int slot,
+                                               int32_t *pixels)
+{
+    int parent;
+    const f3 final = combine_sum(s, f, level, slot, f.refl[slot], parent);
     shade_store(f, level, parent, final, false, pixels);
 }
 
@@ -3080,6 +3100,48 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
 }
 
 // ---------------------------------------------------------------------------------------
+// The sums of every level from level_lo down in ONE launch, for frames whose light terms are all computed ahead
+// (DevFrame::lit with lit_below <= 0) and whose reflecting records carry RT_REFL_PENDING (DevFrame::path_shade).
+// A reflection ray has one child, so the reflecting records of a pixel form a path; the thread of the path's last
+// reflecting record (the one whose child does not reflect: its refl entry is final when this launch starts) sums
+// that record, hands the clamped colour to the parent's sum in a register, and so on up to level_lo, whose result
+// goes where k_shade would put it.  The same sums in the same order as one k_shade launch per level, without the
+// launches' start-up between the levels (~5 us each at the end of the frame, when nothing else runs).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_shade_paths(DevScene s, DevFrame f, int level_lo, int32_t *pixels)
+{
+    __shared__ int na[RT_DEV_MAX_LEVELS];
+    const int deepest = f.max_depth - 1;
+    if ((int)threadIdx.x <= deepest) na[threadIdx.x] = (int)threadIdx.x >= level_lo ? f.cnt[2 * threadIdx.x] : 0;
+    __syncthreads();
+    int total = 0;
+    for (int k = level_lo; k <= deepest; k++) total += na[k];
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        // deepest level first: the longest paths start first
+        int level = deepest, j = i;
+        while (level > level_lo && j >= na[level]) {
+            j -= na[level];
+            level--;
+        }
+        int slot = level * f.P + j;
+        float4 rf = f.refl[slot];
+        if (rf.w == RT_REFL_PENDING) continue;   // the path goes on below this record
+        for (;;) {
+            int parent;
+            f3 final = combine_sum(s, f, level, slot, rf, parent);
+            if (level == level_lo) {
+                shade_store(f, level, parent, final, false, pixels);
+                break;
+            }
+            rf = make_float4(clamp01(final.x), clamp01(final.y), clamp01(final.z), 1.0f);   // as shade_store hands it on
+            slot = parent;
+            level--;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Shading with the lights spread over the waves of a workgroup, for queues too short to fill the
 // device with one record per lane: a lone wave issues an instruction only every ~4.5 cycles, and
 // a record's light loop is one dependent chain of ~400 instructions per light, so a level of a few
@@ -3424,6 +3486,11 @@ void rtk_shade_lights(const DevScene &s, const DevFrame &f, int level, int queue
     const dim3 g(grid_blocks), b(64 * f.light_waves);
     if (f.any_hit == 0) hipLaunchKernelGGL(k_shade_lights<true>, g, b, 0, stream, s, f, level, queue, pixels);
     else hipLaunchKernelGGL(k_shade_lights<false>, g, b, 0, stream, s, f, level, queue, pixels);
+}
+
+void rtk_shade_paths(const DevScene &s, const DevFrame &f, int level_lo, int32_t *pixels, int grid_blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_shade_paths, dim3(grid_blocks), dim3(256), 0, stream, s, f, level_lo, pixels);
 }
 
 void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,

@@ -448,6 +448,42 @@ def test_row_blocks_of_any_number_and_form(monkeypatch, parts, bands):
         assert (fb[0] == -1).all() and (fb[h + 1] == -1).all()
 
 
+@pytest.mark.parametrize("size,depth", [((64, 48), 6), ((640, 400), 6), ((640, 400), 2), ((320, 200), 3)])
+def test_reflecting_records_summed_path_by_path(oracle, monkeypatch, size, depth):
+    """Frames whose light terms are all computed ahead sum their reflecting records in one launch, every pixel's
+    path from its last reflecting record up (the default), instead of one launch per level
+    (RT_HIP_PATH_SHADE=0), or both (=2: the paths down to level 1, then level 0's own launch).  An open scene -
+    mirrors over a mirror floor, no walls - so that paths end in every way: a reflection ray that meets nothing,
+    a child that does not reflect, the depth limit.  The same frame each way, and the restatement's."""
+    mirror = Material(1.0, specular=0.8, diffuseColor=(0.9, 0.9, 1.0, 1.0))
+    half = Material(1.0, specular=0.5, diffuseColor=(1.0, 0.6, 0.2, 1.0))
+    matte = Material(1.0, diffuseColor=(0.3, 0.8, 0.4, 1.0))
+    s = Scene()
+    s.Add(Plane(0.0, -1.0, 0.0, 1.0, mirror))
+    k = 0
+    for ix in range(-3, 4):
+        for iz in range(4):
+            s.Add(Sphere(0.55 * ix, 0.55 - 0.25 * ((ix + iz) % 3), 1.6 + 0.6 * iz, 0.22, (mirror, half, matte)[k % 3]))
+            k += 1
+    s.Add(Light(1.0, -2.0, 0.5))
+    s.Add(Light(-1.5, -1.0, 2.5))
+    fs = s.flatten()
+    cam, (w, h) = Camera(position=(0.0, -0.3, 0.0)), size
+    frames = {}
+    with RenderContext() as c:
+        c.set_scene(fs)
+        for knob in ("", "0", "2"):
+            if knob:
+                monkeypatch.setenv("RT_HIP_PATH_SHADE", knob)
+            c.reload_tuning()
+            frames[knob] = c.render(cam, w, h, depth)
+    ref, _ = oracle.render(fs, cam, w, h, max_depth=depth)
+    assert (ref == 0).any() and ref.any()
+    assert np.array_equal(frames[""], frames["0"])
+    assert np.array_equal(frames["2"], frames["0"])
+    assert_parity(frames[""], ref, "paths summed in one launch")
+
+
 @pytest.mark.parametrize("size,offset", [((1024, 768), 1), ((1024, 768), 3), ((3840, 2160), 1), ((333, 217), 2)])
 def test_framebuffer_at_any_alignment(size, offset):
     """pixels_out is whatever address the host's array has (a managed int[] is 8-byte aligned at
