@@ -229,7 +229,7 @@ __device__ __forceinline__ void load_record(const float4 *a, const float4 *b, fl
 }
 
 // refl[slot].w of a reflecting record: 0 = its ray met nothing, 1 = xyz is the child's colour, and (frames with
-// DevFrame::path_shade) RT_REFL_PENDING = the child reflects too and has not been summed yet.
+// DevFrame::path_shade) RT_REFL_PENDING = the child reflects too and has not been summed yet (mark_parent).
 #define RT_REFL_PENDING 2.0f
 
 // Append up to N new hit records per thread to level `level`, with ONE atomic per queue per
@@ -297,13 +297,6 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
             } else {
                 f.recA[slot] = make_float4(hit[k].x, hit[k].y, hit[k].z, __int_as_float(prim[k]));
                 f.recB[slot] = make_float4(view[k].x, view[k].y, view[k].z, __int_as_float(parent[k]));
-            }
-            // The parent of a record that reflects in its turn is told so (k_shade_paths): after the parent's own
-            // "no reflected colour yet", which this lane stored before the call.
-            if (f.path_shade && level >= 1 && is_a[k]) {
-                uint32_t *w = reinterpret_cast<uint32_t *>(&f.refl[parent[k]]) + 3;
-                if (THROUGH) store_word_through(w, __float_as_uint(RT_REFL_PENDING));
-                else *w = __float_as_uint(RT_REFL_PENDING);
             }
             // Frames whose reflection rays are traced chunk by chunk (k_reflect_chunks) keep the
             // closest hit so far in the first two words of the record's refl slot: nothing yet.
@@ -1848,11 +1841,21 @@ __device__ __forceinline__ size_t lit_first(const DevFrame &f, const int level, 
     return ((size_t)level * (size_t)f.lit_stride + (size_t)(slot - level * f.P)) * (size_t)nl;
 }
 
+// Frames with DevFrame::path_shade: a reflecting record tells its parent that the pixel's path goes on below it
+// (k_shade_paths).  Done where the record's light terms are computed - beside the chain of levels, not on it: in
+// push_records the same store cost the 3840x2160 frame 3 % - and after the parent's "no reflected colour yet",
+// which the launch that created this record stored.
+__device__ __forceinline__ void mark_parent(const DevFrame &f, const int level, const int parent)
+{
+    if (f.path_shade && level >= 1) reinterpret_cast<float *>(&f.refl[parent])[3] = RT_REFL_PENDING;
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void lit_record(const DevScene &s, const DevFrame &f, const int level, const int slot,
                                            const bool active, TestCount &tc)
 {
     const ShadeRecord r = shade_setup(s, f, slot, active, false, false);
+    if (active) mark_parent(f, level, r.parent);
     const int nl = s.nl;
     uint2 cell_next = make_uint2(0u, 0u);
     if (s.lt_n > 0 && nl > 0) cell_next = light_table_cell(s, 0, sub3(r.hit, xyz(cload(s.light_pos, 0))));
@@ -3183,6 +3186,7 @@ __global__ void __launch_bounds__(64 * LIGHT_WAVES_MAX) k_shade_lights(DevScene 
         const int slot = queue_a ? level * f.P + ii : (level + 1) * f.P - 1 - ii;
         const bool through = !queue_a;   // as k_plain and k_shade read and write their records
         const ShadeRecord r = shade_setup(s, f, slot, active, queue_a && !ahead, through);
+        if (ahead && wave == 0 && active) mark_parent(f, level, r.parent);
         f3 final = mk3(0.0f, 0.0f, 0.0f);
         for (int l0 = 0; l0 < nl; l0 += W) {
             const int l = l0 + wave;
