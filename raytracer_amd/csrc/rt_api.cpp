@@ -172,6 +172,9 @@ struct Tuning {
     int early_lights = -1;       // RT_HIP_EARLY_LIGHTS=0 turns the light terms ahead of the children off
     int early_lights_max = 16;   // RT_HIP_EARLY_LIGHTS_MAX: the most lights it is used for
     int early_lights_below = -1; // RT_HIP_EARLY_LIGHTS_BELOW: the bound in records (0: every level)
+    int tail_levels = 0;         // RT_HIP_TAIL_LEVELS=n: the last n levels below the deepest share one launch per kernel,
+                                 // the others have their own
+    int level_group = 0;         // RT_HIP_LEVEL_GROUP=n: scenes of three lights and more, levels per group from the fourth on
     int path_shade = -1;         // RT_HIP_PATH_SHADE=0: one k_shade launch per level even when one launch could sum the paths;
                                  // n > 0: the paths' launch whatever the frame's size, for the levels from n - 1 down
     int reflect_blocks = 8, plain_blocks = 16, light_blocks = 8;   // RT_HIP_REFLECT_BLOCKS / _PLAIN_BLOCKS / _LIGHT_BLOCKS: workgroups per compute unit
@@ -210,6 +213,8 @@ Tuning read_tuning()
     t.early_lights_max = (int)num("RT_HIP_EARLY_LIGHTS_MAX", 16);
     t.early_lights_below = (int)num("RT_HIP_EARLY_LIGHTS_BELOW", -1);
     t.path_shade = (int)num("RT_HIP_PATH_SHADE", -1);
+    t.level_group = (int)num("RT_HIP_LEVEL_GROUP", 0);
+    t.tail_levels = (int)num("RT_HIP_TAIL_LEVELS", 0);
     auto positive = [&](const char *name, int dflt) { const long long v = num(name, 0); return v > 0 ? (int)v : dflt; };
     t.reflect_blocks = positive("RT_HIP_REFLECT_BLOCKS", 8);
     t.plain_blocks = positive("RT_HIP_PLAIN_BLOCKS", 16);
@@ -1978,21 +1983,42 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
             }
             hipStream_t where = k == max_depth ? stream : side;
             if (two_streams && k > 0 && k < max_depth) HIP_TRY(ctx, hipStreamWaitEvent(d.aux, d.ev_level[k - 1], 0));
-            // The two levels below the deepest are small: one launch for both (and their light terms),
-            // issued when the second one's records exist; every launch of its own would add its start-up
-            // to the second stream, which would then end after the chain.
-            const bool tail_pair = two_streams && max_depth >= 3;
-            if (tail_pair && k == max_depth - 2) continue;
-            if (tail_pair && k == max_depth - 1) {
-                rtk_plain_levels(d.scene, f, k - 1, k, dev_pixels, plain_blocks, where);
-                if (f.light_waves) {
-                    rtk_shade_lights(d.scene, f, k - 1, f.lit ? 3 : 0, dev_pixels, light_blocks, where);
-                    rtk_shade_lights(d.scene, f, k, f.lit ? 3 : 0, dev_pixels, light_blocks, where);
+            // Small levels share launches: every launch of its own would add its start-up to the second stream,
+            // which would then end after the chain.  As a rule the two levels below the deepest go in one launch
+            // (and their light terms), issued when the second one's records exist.  Scenes whose rays walk the grid
+            // and whose lights are spread over waves: a short level's launch lasts as long as one record's chain
+            // of lights however few its records (16 lights: ~65 us), the chain is cheap, and the second stream
+            // ends long after it; there the levels from the fourth on go in groups of five, each group issued
+            // when its last level exists (64k spheres, 16 lights, 8 bounces: 2.64 -> 2.45 ms; groups of 2, 3, 4:
+            // 2.55, 2.51, 2.51; the last 7 levels as one: 2.95).  Not elsewhere: 1000 spheres under 8 lights, where
+            // the chain ends last, lose 4 % to groups of any size (3 or 4 lights gain as much).
+            // RT_HIP_TAIL_LEVELS=n (tuning aid): the last n levels as one group, the others on their own;
+            // RT_HIP_LEVEL_GROUP=n: groups of n from the fourth level on, whatever the scene.
+            int group_first = k, group_last = k;
+            if (two_streams && max_depth >= 3 && k < max_depth) {
+                const bool groups = tune.tail_levels <= 0 && f.light_waves && (tune.level_group > 0 || grid);
+                const int first = tune.tail_levels > 0 ? std::max(1, max_depth - tune.tail_levels)
+                                  : groups             ? std::min(3, max_depth - 2)
+                                                       : max_depth - 2;
+                const int per_group = !groups ? max_depth : tune.level_group > 0 ? tune.level_group : 5;
+                if (k >= first) {
+                    group_first = first + (k - first) / per_group * per_group;
+                    group_last = std::min(max_depth - 1, group_first + per_group - 1);
                 }
+            }
+            if (k < group_last) continue;
+            if (group_first < group_last) {
+                rtk_plain_levels(d.scene, f, group_first, k, dev_pixels, plain_blocks, where);
+                // (a pair of levels under more than four lights, outside the grid scenes: a launch each, as measured)
+                if (f.light_waves && (k - group_first > 1 || nl <= 4 || grid))
+                    rtk_shade_lights(d.scene, f, group_first, k, f.lit ? 3 : 0, dev_pixels, light_blocks, where);
+                else if (f.light_waves)
+                    for (int lv = group_first; lv <= k; lv++)
+                        rtk_shade_lights(d.scene, f, lv, lv, f.lit ? 3 : 0, dev_pixels, light_blocks, where);
                 continue;
             }
             rtk_trace(d.scene, f, k, false, dev_pixels, plain_blocks, where);
-            if (f.light_waves) rtk_shade_lights(d.scene, f, k, f.lit && k < max_depth ? 3 : 0, dev_pixels, light_blocks, where);
+            if (f.light_waves) rtk_shade_lights(d.scene, f, k, k, f.lit && k < max_depth ? 3 : 0, dev_pixels, light_blocks, where);
             if (f.lit && k < max_depth) rtk_lit_level(d.scene, f, k, plain_blocks, where);
         }
         if (two_streams) {   // the reflecting records' shading below needs every plain level (and the light terms)
@@ -2012,7 +2038,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     for (int k = (f.path_shade ? path_lo : max_depth) - 1; k >= 0; k--) {
         rtk_shade_level(d.scene, f, k, dev_pixels, std::min(shade_blocks, RT_COUNTER_SLOTS), stream);
         if (f.light_waves && (!f.lit || f.lit_below > 0))
-            rtk_shade_lights(d.scene, f, k, 1, dev_pixels, std::max(1, std::min(d.num_cus * 8 / share, RT_COUNTER_SLOTS)), stream);
+            rtk_shade_lights(d.scene, f, k, k, 1, dev_pixels, std::max(1, std::min(d.num_cus * 8 / share, RT_COUNTER_SLOTS)), stream);
     }
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[3], stream));
     if (part >= 0)

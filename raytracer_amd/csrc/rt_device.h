@@ -275,11 +275,12 @@ void rtk_plain_levels(const DevScene &s, const DevFrame &f, int level_lo, int le
                       hipStream_t stream);
 // The light terms of a level's reflecting records into DevFrame::lit (which must not be null).
 void rtk_lit_level(const DevScene &s, const DevFrame &f, int level, int grid_blocks, hipStream_t stream);
-// A queue of a level with the lights spread over DevFrame::light_waves waves per 64 records; does nothing unless
-// the queue is shorter than DevFrame::light_split_below.  queue 0: the plain records, shaded; 1: the reflecting
-// records, shaded (their children are); 2: the reflecting records' light terms into DevFrame::lit; 3: 0 and 2.
-void rtk_shade_lights(const DevScene &s, const DevFrame &f, int level, int queue, int32_t *pixels, int grid_blocks,
-                      hipStream_t stream);
+// The queues of levels level_lo .. level_hi with the lights spread over DevFrame::light_waves waves per 64 records;
+// does nothing for a queue that is not shorter than DevFrame::light_split_below.  queue 0: the plain records, shaded;
+// 1: the reflecting records, shaded (their children are); 2: the reflecting records' light terms into DevFrame::lit;
+// 3: 0 and 2.
+void rtk_shade_lights(const DevScene &s, const DevFrame &f, int level_lo, int level_hi, int queue, int32_t *pixels,
+                      int grid_blocks, hipStream_t stream);
 // Raytracer.Debug's rays: 16 floats per ray (rt_debug_ray's 14 words, then two of padding).
 void rtk_debug_rays(const DevScene &s, const DevCamera &cam, int row, int x_step, int count, float *out,
                     hipStream_t stream);

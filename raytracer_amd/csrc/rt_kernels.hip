@@ -2826,23 +2826,30 @@ k_plain_tail(DevScene s, DevFrame f, int level, int level_hi, int32_t *pixels)
     // queue's light terms -, so that a workgroup's turns are spread over the queues instead of every workgroup
     // working through one tile of each queue in a row (four chains of dependent reads one after the other: the
     // launch took 37 us for half a million records of the 3840x2160 frame's levels 2 and 3).
-    int total = 0;
-    for (int lv = level; lv <= level_hi; lv++) {
+    // (the queues' lengths once per workgroup, in LDS: read from memory for every job they cost a level of a million
+    // records a third of its time)
+    __shared__ int q_nb[RT_DEV_MAX_LEVELS], q_na[RT_DEV_MAX_LEVELS], q_tiles_b[RT_DEV_MAX_LEVELS], q_tiles_a[RT_DEV_MAX_LEVELS];
+    if ((int)threadIdx.x >= level && (int)threadIdx.x <= level_hi) {
+        const int lv = threadIdx.x;
         const int nb = f.cnt[2 * lv + 1], na = f.cnt[2 * lv];
-        if (!(f.light_waves > 0 && nb < f.light_split_below)) total += (nb + 255) >> 8;   // (else k_shade_lights takes this queue)
-        if (lv < f.max_depth && lit_ahead(f, na) && !(f.light_waves > 0 && na < f.light_split_below)) total += (na + 255) >> 8;
+        q_nb[lv] = nb, q_na[lv] = na;
+        q_tiles_b[lv] = !(f.light_waves > 0 && nb < f.light_split_below) ? (nb + 255) >> 8 : 0;   // (else k_shade_lights takes this queue)
+        q_tiles_a[lv] = lv < f.max_depth && lit_ahead(f, na) && !(f.light_waves > 0 && na < f.light_split_below) ? (na + 255) >> 8 : 0;
     }
+    __syncthreads();
+    int total = 0;
+    for (int lv = level; lv <= level_hi; lv++) total += q_tiles_b[lv] + q_tiles_a[lv];
     for (int job = blockIdx.x; job < total; job += gridDim.x) {
         int tile = job;
         for (int lv = level; lv <= level_hi; lv++) {
-            const int nb = f.cnt[2 * lv + 1], na = f.cnt[2 * lv];
-            const int tiles_b = !(f.light_waves > 0 && nb < f.light_split_below) ? (nb + 255) >> 8 : 0;
+            const int nb = q_nb[lv], na = q_na[lv];
+            const int tiles_b = q_tiles_b[lv];
             if (tile < tiles_b) {
                 plain_tile<COUNT>(s, f, lv, tile, nb, pixels, tc, pc);
                 break;
             }
             tile -= tiles_b;
-            const int tiles_a = lv < f.max_depth && lit_ahead(f, na) && !(f.light_waves > 0 && na < f.light_split_below) ? (na + 255) >> 8 : 0;
+            const int tiles_a = q_tiles_a[lv];
             if (tile < tiles_a) {
                 const int i = tile * 256 + threadIdx.x;
                 lit_record<COUNT>(s, f, lv, lv * f.P + (i < na ? i : na - 1), i < na, tc);
@@ -3157,8 +3164,8 @@ __global__ void __launch_bounds__(256) k_shade_paths(DevScene s, DevFrame f, int
 // ---------------------------------------------------------------------------------------
 #define LIGHT_WAVES_MAX 16
 template <bool COUNT>
-__global__ void __launch_bounds__(64 * LIGHT_WAVES_MAX) k_shade_lights(DevScene s, DevFrame f, int level, int reflecting,
-                                                                      int32_t *pixels)
+__global__ void __launch_bounds__(64 * LIGHT_WAVES_MAX) k_shade_lights(DevScene s, DevFrame f, int level_lo, int level_hi,
+                                                                      int reflecting, int32_t *pixels)
 {
     __shared__ float terms[LIGHT_WAVES_MAX][6][64];
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
@@ -3167,19 +3174,52 @@ __global__ void __launch_bounds__(64 * LIGHT_WAVES_MAX) k_shade_lights(DevScene 
     // long queues; nothing is summed or stored elsewhere); 3: 0 and 2 in one launch (both are chains of dependent
     // reads that a short queue cannot hide: side by side they cost the time of one).
     // Whichever queue is too long for this form, or has its light terms computed the other way, is left out.
-    const int nb = f.cnt[2 * level + 1], na = f.cnt[2 * level];
+    // Levels level_lo .. level_hi in one launch: the tiles of their queues are ONE list of jobs, level by level, the
+    // plain queue and then the reflecting one (a short level's launch is as long as one record's chain of lights:
+    // several levels side by side cost the time of one).
     const bool want_plain = reflecting == 0 || reflecting == 3, want_ahead = reflecting == 2 || reflecting == 3;
-    const int tiles_b = want_plain && nb < f.light_split_below ? (nb + 63) >> 6 : 0;
-    const int tiles_a = (reflecting == 1 && na < f.light_split_below && !lit_ahead(f, na)) ||
-                                (want_ahead && level < f.max_depth && na < f.light_split_below && lit_ahead(f, na))
-                            ? (na + 63) >> 6 : 0;
+    // (the queues' lengths once per workgroup: several levels in LDS, one level - most launches, and the shortest - in
+    // registers: the barrier behind the LDS costs a launch of a few tiles 1.5 us)
+    __shared__ int q_nb[RT_DEV_MAX_LEVELS], q_na[RT_DEV_MAX_LEVELS], q_tiles_b[RT_DEV_MAX_LEVELS], q_tiles_a[RT_DEV_MAX_LEVELS];
+    auto count_tiles = [&](const int lv, const int nb, const int na, int &tiles_b, int &tiles_a) {
+        tiles_b = want_plain && nb < f.light_split_below ? (nb + 63) >> 6 : 0;
+        tiles_a = (reflecting == 1 && na < f.light_split_below && !lit_ahead(f, na)) ||
+                          (want_ahead && lv < f.max_depth && na < f.light_split_below && lit_ahead(f, na))
+                      ? (na + 63) >> 6 : 0;
+    };
+    const bool one_level = level_lo == level_hi;
+    int one_nb = 0, one_na = 0, one_tiles_b = 0, one_tiles_a = 0, total = 0;
+    if (one_level) {
+        one_nb = f.cnt[2 * level_lo + 1], one_na = f.cnt[2 * level_lo];
+        count_tiles(level_lo, one_nb, one_na, one_tiles_b, one_tiles_a);
+        total = one_tiles_b + one_tiles_a;
+    } else {
+        if ((int)threadIdx.x >= level_lo && (int)threadIdx.x <= level_hi) {
+            const int lv = threadIdx.x;
+            const int nb = f.cnt[2 * lv + 1], na = f.cnt[2 * lv];
+            q_nb[lv] = nb, q_na[lv] = na;
+            count_tiles(lv, nb, na, q_tiles_b[lv], q_tiles_a[lv]);
+        }
+        __syncthreads();
+        for (int lv = level_lo; lv <= level_hi; lv++) total += q_tiles_b[lv] + q_tiles_a[lv];
+    }
+    auto tiles_of = [&](const int lv, int &tiles_b, int &tiles_a, int &nb, int &na) {
+        if (one_level) nb = one_nb, na = one_na, tiles_b = one_tiles_b, tiles_a = one_tiles_a;
+        else nb = q_nb[lv], na = q_na[lv], tiles_b = q_tiles_b[lv], tiles_a = q_tiles_a[lv];
+    };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
     const int nl = s.nl;
     TestCount tc = {0, 0, 0, 0, 0, 0, 0};
-    for (int job = blockIdx.x; job < tiles_b + tiles_a; job += gridDim.x) {
-        const bool queue_a = job >= tiles_b;              // (uniform over the workgroup)
+    for (int job = blockIdx.x; job < total; job += gridDim.x) {
+        int level = level_lo, tiles_b, tiles_a, nb, na, in_level = job;
+        for (;; level++) {   // (ends: job < total)
+            tiles_of(level, tiles_b, tiles_a, nb, na);
+            if (in_level < tiles_b + tiles_a) break;
+            in_level -= tiles_b + tiles_a;
+        }
+        const bool queue_a = in_level >= tiles_b;              // (uniform over the workgroup)
         const bool ahead = queue_a && want_ahead;
-        const int tile = queue_a ? job - tiles_b : job, n = queue_a ? na : nb;
+        const int tile = queue_a ? in_level - tiles_b : in_level, n = queue_a ? na : nb;
         const int i = tile * 64 + lane;
         const bool active = i < n;
         const int ii = active ? i : n - 1;
@@ -3484,12 +3524,12 @@ void rtk_lit_level(const DevScene &s, const DevFrame &f, int level, int grid_blo
     else hipLaunchKernelGGL(k_lit<false>, dim3(grid_blocks), dim3(256), 0, stream, s, f, level);
 }
 
-void rtk_shade_lights(const DevScene &s, const DevFrame &f, int level, int queue, int32_t *pixels, int grid_blocks,
-                      hipStream_t stream)
+void rtk_shade_lights(const DevScene &s, const DevFrame &f, int level_lo, int level_hi, int queue, int32_t *pixels,
+                      int grid_blocks, hipStream_t stream)
 {
     const dim3 g(grid_blocks), b(64 * f.light_waves);
-    if (f.any_hit == 0) hipLaunchKernelGGL(k_shade_lights<true>, g, b, 0, stream, s, f, level, queue, pixels);
-    else hipLaunchKernelGGL(k_shade_lights<false>, g, b, 0, stream, s, f, level, queue, pixels);
+    if (f.any_hit == 0) hipLaunchKernelGGL(k_shade_lights<true>, g, b, 0, stream, s, f, level_lo, level_hi, queue, pixels);
+    else hipLaunchKernelGGL(k_shade_lights<false>, g, b, 0, stream, s, f, level_lo, level_hi, queue, pixels);
 }
 
 void rtk_shade_paths(const DevScene &s, const DevFrame &f, int level_lo, int32_t *pixels, int grid_blocks, hipStream_t stream)
