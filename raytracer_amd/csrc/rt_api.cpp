@@ -91,6 +91,7 @@ thread_local char g_create_error[RT_ERROR_CHARS] = "";
 // every few tens of microseconds), short enough that a lost frame is reported at once.
 constexpr unsigned RT_STALL_MS_DEFAULT = 1000;
 constexpr size_t RT_LIT_MAX_BYTES = (size_t)16 << 30;
+constexpr int RT_LIGHT_SPLIT_LARGE_SCENE = 32768;   // spheres (padded) from which long queues too are shaded with the lights spread
 
 struct DeviceState {
     int device = 0;
@@ -1847,7 +1848,13 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // (The more lights, the longer the queues it pays for: a wave of k_shade_lights looks one light up for 64
     // neighbouring records - one table, nearby cells - where a lane of k_plain goes through all the tables.
     // 16 lights: 4.04 ms per frame with queues below 64 K records, 3.88 below 256 K, 3.64 below 512 K or 1 M, 4.3 for all.)
-    fr.light_split_below = light_below_env > 0 ? light_below_env : std::max(64, 32 * nl) * 1024 / share;
+    // That is the 64k-sphere scene, whose tables are large and whose light rays wait for memory: the sixteen times as
+    // many waves hide it.  With smaller tables the spread form's repeated work (every wave sets the record up) is what
+    // counts - 16 lights at 1920x1080, depth 6, bounds of 512 K against 64 K records: 2048 spheres 0.858 / 0.732 ms,
+    // 4096: 1.193 / 0.965, 16384: 1.415 / 1.236, 32768: the same, 49152: 2.23 at 256 K against 2.42 at 64 K - so
+    // scenes of fewer than RT_LIGHT_SPLIT_LARGE_SCENE spheres spread the lights only for queues below 64 K records.
+    const int light_below_default = d.scene.ns_padded < RT_LIGHT_SPLIT_LARGE_SCENE ? 65536 : std::max(64, 32 * nl) * 1024;
+    fr.light_split_below = light_below_env > 0 ? light_below_env : light_below_default / share;
     // Scenes of several chunks or many lights, one launch per level: the records of a level >= 1 are put
     // into the order of their hit points' position bins before the level is used (k_bin_*).
     // RT_HIP_BIN_MIN=n (tuning aid): for levels of at least n records; 0 = never.
