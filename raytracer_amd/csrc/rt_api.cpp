@@ -178,7 +178,8 @@ struct Tuning {
     int level_group = 0;         // RT_HIP_LEVEL_GROUP=n: scenes of three lights and more, levels per group from the fourth on
     int path_shade = -1;         // RT_HIP_PATH_SHADE=0: one k_shade launch per level even when one launch could sum the paths;
                                  // n > 0: the paths' launch whatever the frame's size, for the levels from n - 1 down
-    int reflect_blocks = 8, plain_blocks = 16, light_blocks = 8;   // RT_HIP_REFLECT_BLOCKS / _PLAIN_BLOCKS / _LIGHT_BLOCKS: workgroups per compute unit
+    int reflect_blocks = 0, plain_blocks = 16, light_blocks = 16;   // RT_HIP_REFLECT_BLOCKS / _PLAIN_BLOCKS / _LIGHT_BLOCKS: workgroups per
+                                                                    // compute unit (reflect_blocks 0: 8, or 4 for the grid walk)
     size_t copy_chunk_pixels = 0;   // RT_HIP_COPY_CHUNK_KIB
     int frame_parts = 0;         // RT_HIP_FRAME_PARTS: row blocks of rt_render's frame on one device
     int part_bands = -1;         // RT_HIP_PART_BANDS=0: contiguous row blocks instead of interleaved bands
@@ -217,9 +218,9 @@ Tuning read_tuning()
     t.level_group = (int)num("RT_HIP_LEVEL_GROUP", 0);
     t.tail_levels = (int)num("RT_HIP_TAIL_LEVELS", 0);
     auto positive = [&](const char *name, int dflt) { const long long v = num(name, 0); return v > 0 ? (int)v : dflt; };
-    t.reflect_blocks = positive("RT_HIP_REFLECT_BLOCKS", 8);
+    t.reflect_blocks = positive("RT_HIP_REFLECT_BLOCKS", 0);
     t.plain_blocks = positive("RT_HIP_PLAIN_BLOCKS", 16);
-    t.light_blocks = positive("RT_HIP_LIGHT_BLOCKS", 8);
+    t.light_blocks = positive("RT_HIP_LIGHT_BLOCKS", 16);
     t.copy_chunk_pixels = (size_t)std::max(0ll, num("RT_HIP_COPY_CHUNK_KIB", 0)) * 256;
     t.frame_parts = (int)num("RT_HIP_FRAME_PARTS", 0);
     t.part_bands = (int)num("RT_HIP_PART_BANDS", -1);
@@ -1843,7 +1844,9 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // over the waves of a workgroup (k_shade_lights).  RT_HIP_LIGHT_SPLIT_BELOW=n (tuning aid; 0 = never).
     const int light_below_env = tune.light_split_below;
     const int nl = d.scene.nl;
-    fr.light_waves = fused || nl < 3 || light_below_env == 0 ? 0 : nl >= 12 ? 16 : nl >= 6 ? 8 : 4;
+    // (16 lights over 16 waves: 2.44 ms for the 64k-sphere frame; over 12, 10, 8, 7, 6, 5, 4: 2.64, 2.60, 2.36, 2.28, 2.29,
+    // 2.29, 2.37 - a workgroup of six waves leaves room for more of them on a compute unit)
+    fr.light_waves = fused || nl < 3 || light_below_env == 0 ? 0 : nl >= 6 ? 6 : 4;
     if (fr.light_waves && tune.light_waves >= 1 && tune.light_waves <= 16) fr.light_waves = tune.light_waves;   // RT_HIP_LIGHT_WAVES
     // (The more lights, the longer the queues it pays for: a wave of k_shade_lights looks one light up for 64
     // neighbouring records - one table, nearby cells - where a lane of k_plain goes through all the tables.
@@ -1946,7 +1949,10 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[0], stream));
     // Workgroups per compute unit of the per-level launches (RT_HIP_REFLECT_BLOCKS / RT_HIP_PLAIN_BLOCKS /
     // RT_HIP_LIGHT_BLOCKS, tuning aids, override the defaults).
-    const int blocks = std::max(1, std::min({(P + 255) / 256, d.num_cus * tune.reflect_blocks / std::max(1, ctx->share),
+    // (the grid walk refills its lanes from a tile of 512 records: fewer, longer-lived workgroups; 64k spheres, 16 lights:
+    // 2.37 ms with 8 per compute unit, 2.34 with 4, 2.45 with 2)
+    const int reflect_blocks = tune.reflect_blocks > 0 ? tune.reflect_blocks : grid ? 4 : 8;
+    const int blocks = std::max(1, std::min({(P + 255) / 256, d.num_cus * reflect_blocks / std::max(1, ctx->share),
                                              RT_COUNTER_SLOTS}));
     // k_primary's workgroups claim their 32x32-pixel tiles dynamically: as many workgroups as are
     // resident at once (4 per compute unit) when each gets several tiles, twice that on small frames
