@@ -91,6 +91,8 @@ thread_local char g_create_error[RT_ERROR_CHARS] = "";
 // every few tens of microseconds), short enough that a lost frame is reported at once.
 constexpr unsigned RT_STALL_MS_DEFAULT = 1000;
 constexpr size_t RT_LIT_MAX_BYTES = (size_t)16 << 30;
+constexpr size_t RT_STATUS_BYTES = 256;   // DevFrame::status (16 words), then DevFrame::hint (a tag and 2 words per level)
+static_assert(64 + sizeof(int) * (1 + 2 * RT_DEV_MAX_LEVELS) <= RT_STATUS_BYTES, "the hint block holds every level's counts");
 constexpr int RT_LIGHT_SPLIT_LARGE_SCENE = 32768;   // spheres (padded) from which long queues too are shaded with the lights spread
 
 struct DeviceState {
@@ -176,6 +178,7 @@ struct Tuning {
     int tail_levels = 0;         // RT_HIP_TAIL_LEVELS=n: the last n levels below the deepest share one launch per kernel,
                                  // the others have their own
     int level_group = 0;         // RT_HIP_LEVEL_GROUP=n: scenes of three lights and more, levels per group from the fourth on
+    int bin_hint = -1;           // RT_HIP_BIN_HINT=0: every level goes through the binning launches, whatever the last frame's counts
     int path_shade = -1;         // RT_HIP_PATH_SHADE=0: one k_shade launch per level even when one launch could sum the paths;
                                  // n > 0: the paths' launch whatever the frame's size, for the levels from n - 1 down
     int reflect_blocks = 0, plain_blocks = 16, light_blocks = 16;   // RT_HIP_REFLECT_BLOCKS / _PLAIN_BLOCKS / _LIGHT_BLOCKS: workgroups per
@@ -215,6 +218,7 @@ Tuning read_tuning()
     t.early_lights_max = (int)num("RT_HIP_EARLY_LIGHTS_MAX", 16);
     t.early_lights_below = (int)num("RT_HIP_EARLY_LIGHTS_BELOW", -1);
     t.path_shade = (int)num("RT_HIP_PATH_SHADE", -1);
+    t.bin_hint = (int)num("RT_HIP_BIN_HINT", -1);
     t.level_group = (int)num("RT_HIP_LEVEL_GROUP", 0);
     t.tail_levels = (int)num("RT_HIP_TAIL_LEVELS", 0);
     auto positive = [&](const char *name, int dflt) { const long long v = num(name, 0); return v > 0 ? (int)v : dflt; };
@@ -249,6 +253,7 @@ struct rt_ctx {
     std::vector<DeviceState> dev;
     char error[RT_ERROR_CHARS] = "";
     bool have_scene = false;
+    unsigned scene_serial = 0;     // counts rt_set_scene calls (hints of one scene's frames say nothing about another's)
     bool wedged = false;           // a device did not come back within the time limit: nothing of this context may wait for it again
     int profiling = 0;             // RT_PROFILE_*: 0 off, 1 counters and event timing, 2 event timing only
     int share = 1;                 // contexts rendering on this context's devices at the same time (rt_set_device_share)
@@ -1474,8 +1479,8 @@ hipError_t create_device_objects(DeviceState &d, bool aux_low_priority)
     if (e == hipSuccess && !d.aux) e = hipStreamCreateWithFlags(&d.aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming);
     for (int k = 0; k <= RT_MAX_DEPTH && e == hipSuccess; k++) e = hipEventCreateWithFlags(&d.ev_level[k], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&d.status, 64, hipHostMallocMapped);
-    if (e == hipSuccess) memset(d.status, 0, 64);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&d.status, RT_STATUS_BYTES, hipHostMallocMapped);
+    if (e == hipSuccess) memset(d.status, 0, RT_STATUS_BYTES);
     if (e == hipSuccess) e = scratch_address(d.device, &d.scratch_base);
     if (e == hipSuccess) e = hipMalloc((void **)&d.probe, 64);
     return e;
@@ -1892,11 +1897,32 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
         if (stride <= d.cap_bin && d.bin_hist && d.spare_level) {
             fr.bin_min = bin_min_env > 0 ? bin_min_env : 16384;
             fr.stage_base = (max_depth + 1) * fr.P;   // (the spare level: ensure_frame)
-            fr.staged = grid ? 1 : 0;
             fr.bin_aux = d.bin_aux;
             fr.bin_hist = d.bin_hist;
             fr.bin_base = d.bin_hist + 2 * RT_BINS;
         }
+    }
+    // Which levels go through the binning launches (bit k: level k).  A level below bin_min records is not put into
+    // order, but its three or four launches still stand on the chain (~10 us each: a rank's eighth of the 64k-sphere
+    // frame spent a quarter of its time on them).  The frame's last launch leaves the levels' record counts in
+    // page-locked memory (DevFrame::hint); a level that held fewer than half of bin_min records in the last finished
+    // frame of this scene, size and depth is pushed straight to its slots this time and has no binning launches.  Only
+    // speed depends on the hint: a level left out is a level that is not put into order, whatever its length turns out
+    // to be, and the counts keep coming, so it is taken in again when it grows.  RT_HIP_BIN_HINT=0 (tuning aid): every level.
+    unsigned bin_levels = 0;
+    fr.hint = nullptr;
+    fr.hint_tag = 0;
+    if (fr.bin_min > 0) {
+        bin_levels = ~0u;
+        if (d.status && tune.bin_hint != 0) {
+            fr.hint = d.status + 16;
+            fr.hint_tag = (int)(((ctx->scene_serial * 2654435761u) ^ ((unsigned)P * 40503u) ^ ((unsigned)max_depth * 97u)) | 1u);
+            const volatile int *hint = fr.hint;
+            if (hint[0] == fr.hint_tag)
+                for (int k = 1; k <= max_depth; k++)
+                    if (hint[1 + 2 * k] + hint[2 + 2 * k] < fr.bin_min / 2) bin_levels &= ~(1u << k);
+        }
+        fr.staged = grid ? (int)(bin_levels & 0x7fffffffu) : 0;
     }
     // Scenes with few lights, one launch per level: the reflecting records' light terms are computed
     // beside the plain records' shading (k_lit), so that the passes at the end of the frame, which
@@ -1991,7 +2017,8 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
             if (k < max_depth) {
                 rtk_trace(d.scene, f, k, true, dev_pixels, blocks, stream);
                 if (f.split_chunks) rtk_reflect_chunks(d.scene, f, k, std::max(1, d.num_cus * 4 / share), blocks, stream);
-                if (f.bin_min > 0) rtk_bin_level(d.scene, f, k + 1, std::max(1, d.num_cus * 8 / share), stream);
+                if (f.bin_min > 0 && ((bin_levels >> (k + 1)) & 1u))
+                    rtk_bin_level(d.scene, f, k + 1, std::max(1, d.num_cus * 8 / share), stream);
                 if (two_streams) HIP_TRY(ctx, hipEventRecord(d.ev_level[k], stream));
             }
             hipStream_t where = k == max_depth ? stream : side;
@@ -2216,6 +2243,7 @@ int rt_set_scene(rt_ctx *ctx, const rt_scene *s)
     ctx->nt = (int)ps.tri_orig.size();
     ctx->textures_used = ps.textures_used;
     ctx->have_scene = true;
+    ctx->scene_serial++;
     return RT_OK;
     });
 }

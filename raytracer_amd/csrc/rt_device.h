@@ -216,6 +216,10 @@ struct DevFrame {
     // when something went wrong): status[0] != 0 = a workgroup of k_trace_levels gave up waiting
     // for a level to open, status[1] = that level.  Never cleared by the device.
     int *status;
+    // Page-locked host memory too, or null: what the last launch of a frame tells the host about the frame, as a hint for
+    // how to launch the next one (hint[0] = hint_tag, hint[1 + i] = cnt[i]); nothing's correctness rests on it.
+    int *hint;
+    int hint_tag;
     unsigned stall_ticks;  // how long a workgroup waits without progress, in ticks of the 100 MHz wall clock
     int debug_withhold;    // test knob: the first reflecting tile of this level is never counted as done (-1: off)
     // Records of a level >= 1 put into the order of their hit points' position bins before the level is
@@ -224,7 +228,7 @@ struct DevFrame {
     uint2 *bin_aux;        // per record of the level being binned: {bin, rank within the bin}
     int stage_base;        // frames with bin_min > 0: first slot of a spare level of recA / recB behind the last one,
                            // what the binning passes move a level's records through
-    int staged;            // 1: the records of a level >= 1 are first written there (laid out like a level; the grid
+    int staged;            // bit k: the records of level k >= 1 are first written there (laid out like a level; the grid
                            // walk's launches), and k_bin_scatter moves them to the level's own slots
     int *bin_hist;         // [2 * RT_BINS] records per bin (reflecting queue, plain queue); zero between uses
     int *bin_base;         // [2 * RT_BINS] first position of each bin in its queue

@@ -284,7 +284,7 @@ __device__ __forceinline__ void push_records(const DevFrame &f, const DevScene &
     const int base_a = blk[2 * nwaves] + blk[2 * wave], base_b = blk[2 * nwaves + 1] + blk[2 * wave + 1];
     // STAGE (the grid walk's launches): a frame whose deeper levels are put into bin order stages their records in
     // a spare level (DevFrame::staged, stage_base); k_bin_scatter moves them to their slots.
-    const int first = STAGE && f.staged && level >= 1 ? f.stage_base : level * f.P;
+    const int first = STAGE && level >= 1 && ((f.staged >> level) & 1) ? f.stage_base : level * f.P;
 #pragma unroll
     for (int k = 0; k < N; k++) {
         if (valid[k]) {
@@ -3092,6 +3092,12 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
 {
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int na = f.cnt[2 * level];
+    // The frame's last launch leaves the levels' record counts where the host can read them without asking the device
+    // (DevFrame::hint).
+    if (level == 0 && f.hint != nullptr && blockIdx.x == 0 && (int)threadIdx.x <= 2 * (f.max_depth + 1)) {
+        const int v = threadIdx.x == 0 ? f.hint_tag : f.cnt[threadIdx.x - 1];
+        __hip_atomic_store(&f.hint[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (lit_ahead(f, na)) {   // the light terms are there (k_lit): only the sums are left
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na; i += gridDim.x * blockDim.x)
             combine_record(s, f, level, level * f.P + i, pixels);

@@ -356,6 +356,38 @@ def test_config5_64k_spheres_16_lights_depth8(ctx, oracle):
         assert st[k] == cnt[k], k
 
 
+@pytest.mark.parametrize("scene_kind", ["grid16", "plain8"])
+def test_binning_launches_left_out_on_the_last_frames_counts(monkeypatch, scene_kind):
+    """Scenes whose deeper levels are put into bin order: the frame's last launch leaves the levels' record counts in
+    page-locked memory, and the next frame of the same scene, size and depth leaves the binning launches of its
+    short levels out (grid scenes: pushes those levels' records straight to their slots).  Only speed may depend
+    on that: frames of one context in a row - sizes alternating, so that hints come and go and a level is binned in
+    one frame and not in the next - are those of contexts that never use the hint (RT_HIP_BIN_HINT=0), and with the
+    binning bound lowered so that every size has levels on both sides of it."""
+    if scene_kind == "grid16":
+        fs = synthetic_scene(3000, radius=(0.02, 0.08), seed=91, lights="grid16").flatten()   # grid walk, staged records
+    else:
+        sc = synthetic_scene(1000, seed=5)                                                     # filter loops, 8 lights
+        sc.lights.clear()
+        for i in range(8):
+            sc.Add(Light(-2.0 + 0.6 * i, -1.0, 0.5 + 0.3 * i))
+        fs = sc.flatten()
+    cam, depth = Camera(), 5
+    sizes = [(320, 180), (320, 180), (96, 54), (320, 180), (320, 180), (640, 360), (640, 360), (320, 180)]
+    monkeypatch.setenv("RT_HIP_BIN_MIN", "2000")
+    monkeypatch.setenv("RT_HIP_BIN_HINT", "0")
+    with RenderContext() as c:
+        c.set_scene(fs)
+        plain = {size: c.render(cam, size[0], size[1], depth) for size in set(sizes)}
+    monkeypatch.delenv("RT_HIP_BIN_HINT")
+    with RenderContext() as c:
+        c.set_scene(fs)
+        for i, (w, h) in enumerate(sizes):
+            assert np.array_equal(c.render(cam, w, h, depth), plain[(w, h)]), (i, w, h)
+        c.set_scene(fs)   # (a new scene: the counts of the old one's frames say nothing)
+        assert np.array_equal(c.render(cam, 320, 180, depth), plain[(320, 180)])
+
+
 @pytest.mark.parametrize("nspheres,nl,depth,size", [(1500, 2, 3, (160, 90)), (1025, 5, 2, (96, 54)),
                                                     (2048, 0, 2, (64, 36)), (132000, 2, 2, (40, 24))])
 def test_chunked_scenes(ctx, oracle, nspheres, nl, depth, size):
