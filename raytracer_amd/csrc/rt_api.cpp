@@ -1909,21 +1909,22 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // frame of this scene, size and depth is pushed straight to its slots this time and has no binning launches.  Only
     // speed depends on the hint: a level left out is a level that is not put into order, whatever its length turns out
     // to be, and the counts keep coming, so it is taken in again when it grows.  RT_HIP_BIN_HINT=0 (tuning aid): every level.
-    unsigned bin_levels = 0;
+    // The same counts tell which levels' reflecting records will have their light terms ahead (fewer than lit_below):
+    // the passes at the end of the frame then issue one launch for such a level instead of two (lit_small, below).
+    unsigned bin_levels = fr.bin_min > 0 ? ~0u : 0u, lit_small = 0u;
     fr.hint = nullptr;
     fr.hint_tag = 0;
-    if (fr.bin_min > 0) {
-        bin_levels = ~0u;
-        if (d.status && tune.bin_hint != 0) {
-            fr.hint = d.status + 16;
-            fr.hint_tag = (int)(((ctx->scene_serial * 2654435761u) ^ ((unsigned)P * 40503u) ^ ((unsigned)max_depth * 97u)) | 1u);
-            const volatile int *hint = fr.hint;
-            if (hint[0] == fr.hint_tag)
-                for (int k = 1; k <= max_depth; k++)
-                    if (hint[1 + 2 * k] + hint[2 + 2 * k] < fr.bin_min / 2) bin_levels &= ~(1u << k);
-        }
-        fr.staged = grid ? (int)(bin_levels & 0x7fffffffu) : 0;
+    if ((fr.bin_min > 0 || fr.light_waves > 0) && d.status && tune.bin_hint != 0 && !fixed_scratch) {
+        fr.hint = d.status + 16;
+        fr.hint_tag = (int)(((ctx->scene_serial * 2654435761u) ^ ((unsigned)P * 40503u) ^ ((unsigned)max_depth * 97u)) | 1u);
+        const volatile int *hint = fr.hint;
+        if (hint[0] == fr.hint_tag)
+            for (int k = 0; k <= max_depth; k++) {
+                if (k >= 1 && hint[1 + 2 * k] + hint[2 + 2 * k] < fr.bin_min / 2) bin_levels &= ~(1u << k);
+                if (hint[1 + 2 * k] < 32768) lit_small |= 1u << k;
+            }
     }
+    if (fr.bin_min > 0) fr.staged = grid ? (int)(bin_levels & 0x7fffffffu) : 0;
     // Scenes with few lights, one launch per level: the reflecting records' light terms are computed
     // beside the plain records' shading (k_lit), so that the passes at the end of the frame, which
     // nothing can overlap, only add them up.  Costs 16 bytes per slot of the levels below max_depth and
@@ -2076,8 +2077,11 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // (the reflecting records; the deepest level has none)
     if (f.path_shade) rtk_shade_paths(d.scene, f, path_lo, dev_pixels, std::min(shade_blocks, RT_COUNTER_SLOTS), stream);
     for (int k = (f.path_shade ? path_lo : max_depth) - 1; k >= 0; k--) {
-        rtk_shade_level(d.scene, f, k, dev_pixels, std::min(shade_blocks, RT_COUNTER_SLOTS), stream);
-        if (f.light_waves && (!f.lit || f.lit_below > 0))
+        // (a level whose light terms are expected to be there - a hint - gets the one launch, which then takes the queue
+        // whatever it turns out to be; lit_below is 65536 when it is positive, and the hint asks for half of that)
+        const bool alone = f.lit && f.lit_below >= 65536 && ((lit_small >> k) & 1u);
+        rtk_shade_level(d.scene, f, k, alone, dev_pixels, std::min(shade_blocks, RT_COUNTER_SLOTS), stream);
+        if (f.light_waves && (!f.lit || f.lit_below > 0) && !alone)
             rtk_shade_lights(d.scene, f, k, k, 1, dev_pixels, std::max(1, std::min(d.num_cus * 8 / share, RT_COUNTER_SLOTS)), stream);
     }
     if (d.timed) HIP_TRY(ctx, hipEventRecord(d.ev[3], stream));

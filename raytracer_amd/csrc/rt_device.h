@@ -268,7 +268,8 @@ void rtk_bin_level(const DevScene &s, const DevFrame &f, int level, int grid_blo
 // (of the instance rtk_trace_levels launches for a frame with that chain policy / counting mode)
 int rtk_trace_levels_resident_blocks(const DevScene &s, int num_cus, bool reserve, bool count);
 void rtk_trace_levels(const DevScene &s, const DevFrame &f, int32_t *pixels, int grid_blocks, hipStream_t stream);
-void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
+// alone: no rtk_shade_lights(level, 1) follows; the launch then shades the queue whatever its length.
+void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, bool alone, int32_t *pixels,
                      int grid_blocks, hipStream_t stream);
 // The sums of the reflecting records of every level from level_lo down, path by path (needs DevFrame::path_shade
 // and the light terms of all those levels in DevFrame::lit).

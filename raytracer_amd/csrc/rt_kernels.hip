@@ -3088,7 +3088,7 @@ k_trace_levels(DevScene s, DevFrame f, int32_t *pixels)
 // by the level kernel.
 // ---------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level, int32_t *pixels)
+__global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level, int alone, int32_t *pixels)
 {
     __shared__ unsigned long long cnt_sh[COUNTER_WORDS];
     const int na = f.cnt[2 * level];
@@ -3103,7 +3103,9 @@ __global__ void __launch_bounds__(256) k_shade(DevScene s, DevFrame f, int level
             combine_record(s, f, level, level * f.P + i, pixels);
         return;
     }
-    if (f.light_waves > 0 && na < f.light_split_below) return;   // k_shade_lights takes this queue
+    // k_shade_lights takes this queue - unless the host has issued no such launch for this level (alone: it expects the
+    // light terms to be there, on a hint; whatever the queue turns out to be, it is shaded here)
+    if (!alone && f.light_waves > 0 && na < f.light_split_below) return;
     const int stride = gridDim.x * blockDim.x;
     TestCount tc = {0, 0, 0, 0, 0, 0, 0};
     // (whole waves: the light rays of a record are traced by its wave together)
@@ -3543,9 +3545,9 @@ void rtk_shade_paths(const DevScene &s, const DevFrame &f, int level_lo, int32_t
     hipLaunchKernelGGL(k_shade_paths, dim3(grid_blocks), dim3(256), 0, stream, s, f, level_lo, pixels);
 }
 
-void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, int32_t *pixels,
+void rtk_shade_level(const DevScene &s, const DevFrame &f, int level, bool alone, int32_t *pixels,
                      int grid_blocks, hipStream_t stream)
 {
-    if (f.any_hit == 0) hipLaunchKernelGGL(k_shade<true>, dim3(grid_blocks), dim3(256), 0, stream, s, f, level, pixels);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(grid_blocks), dim3(256), 0, stream, s, f, level, pixels);
+    if (f.any_hit == 0) hipLaunchKernelGGL(k_shade<true>, dim3(grid_blocks), dim3(256), 0, stream, s, f, level, alone ? 1 : 0, pixels);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(grid_blocks), dim3(256), 0, stream, s, f, level, alone ? 1 : 0, pixels);
 }

@@ -388,6 +388,28 @@ def test_binning_launches_left_out_on_the_last_frames_counts(monkeypatch, scene_
         assert np.array_equal(c.render(cam, 320, 180, depth), plain[(320, 180)])
 
 
+def test_a_wrong_hint_costs_speed_only(monkeypatch):
+    """The 64k-sphere scene under 16 lights, 1280x720: looking at the back wall no record reflects, so the counts the
+    frame leaves behind promise short queues everywhere; the next frame looks at the spheres, 300 000 reflecting
+    records at level 0 - a queue that the launch with the lights spread over waves would take, had the host issued
+    it.  The one launch it did issue shades the queue all the same: every frame of the sequence is the frame of a
+    context that uses no hints."""
+    from raytracer_amd import scene_64k
+    fs = scene_64k().flatten()
+    back, front = Camera(direction=(0.0, 0.0, -1.0)), Camera()
+    w, h, depth = 1280, 720, 8
+    monkeypatch.setenv("RT_HIP_BIN_HINT", "0")
+    with RenderContext() as c:
+        c.set_scene(fs)
+        plain = {id(cam): c.render(cam, w, h, depth) for cam in (back, front)}
+    monkeypatch.delenv("RT_HIP_BIN_HINT")
+    assert plain[id(front)].any() and not np.array_equal(plain[id(front)], plain[id(back)])
+    with RenderContext() as c:
+        c.set_scene(fs)
+        for i, cam in enumerate((back, back, front, front, back, front)):
+            assert np.array_equal(c.render(cam, w, h, depth), plain[id(cam)]), i
+
+
 @pytest.mark.parametrize("nspheres,nl,depth,size", [(1500, 2, 3, (160, 90)), (1025, 5, 2, (96, 54)),
                                                     (2048, 0, 2, (64, 36)), (132000, 2, 2, (40, 24))])
 def test_chunked_scenes(ctx, oracle, nspheres, nl, depth, size):
