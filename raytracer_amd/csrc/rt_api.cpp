@@ -2075,7 +2075,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
     // (measured at 3840x2160: 0.128 ms against 0.145 with 8 and 0.143 with 128).
     const int shade_blocks = std::max(1, std::min((P + 255) / 256, d.num_cus * 32));
     // (the reflecting records; the deepest level has none)
-    if (f.path_shade) rtk_shade_paths(d.scene, f, path_lo, dev_pixels, std::min(shade_blocks, RT_COUNTER_SLOTS), stream);
+    if (f.path_shade) rtk_shade_paths(d.scene, f, path_lo, dev_pixels, shade_blocks, stream);   // (keeps no counters)
     for (int k = (f.path_shade ? path_lo : max_depth) - 1; k >= 0; k--) {
         // (a level whose light terms are expected to be there - a hint - gets the one launch, which then takes the queue
         // whatever it turns out to be; lit_below is 65536 when it is positive, and the hint asks for half of that)
