@@ -2025,19 +2025,18 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
             hipStream_t where = k == max_depth ? stream : side;
             if (two_streams && k > 0 && k < max_depth) HIP_TRY(ctx, hipStreamWaitEvent(d.aux, d.ev_level[k - 1], 0));
             // Small levels share launches: every launch of its own would add its start-up to the second stream,
-            // which would then end after the chain.  As a rule the two levels below the deepest go in one launch
-            // (and their light terms), issued when the second one's records exist.  Scenes whose rays walk the grid
-            // and whose lights are spread over waves: a short level's launch lasts as long as one record's chain
-            // of lights however few its records (16 lights: ~65 us), the chain is cheap, and the second stream
-            // ends long after it; there the levels from the fourth on go in groups of five, each group issued
-            // when its last level exists (64k spheres, 16 lights, 8 bounces: 2.64 -> 2.45 ms; groups of 2, 3, 4:
-            // 2.55, 2.51, 2.51; the last 7 levels as one: 2.95).  Not elsewhere: 1000 spheres under 8 lights, where
-            // the chain ends last, lose 4 % to groups of any size (3 or 4 lights gain as much).
+            // which would then end after the chain.  Scenes of one or two lights: the two levels below the deepest
+            // go in one launch (and their light terms), issued when the second one's records exist.  With the lights
+            // spread over waves (three lights and more) a short level's launch lasts as long as one record's chain of
+            // lights however few its records (16 lights: ~65 us): there the levels from the fourth on go in groups
+            // of five, each group issued when its last level exists (64k spheres, 16 lights, 8 bounces: 2.64 -> 2.45
+            // ms; groups of 2, 3, 4: 2.55, 2.51, 2.51; the last 7 levels as one: 2.95; 1000 spheres under 3, 4, 8 lights
+            // at 1920x1080, depth 8: 2, 4.5, 4 % faster).
             // RT_HIP_TAIL_LEVELS=n (tuning aid): the last n levels as one group, the others on their own;
-            // RT_HIP_LEVEL_GROUP=n: groups of n from the fourth level on, whatever the scene.
+            // RT_HIP_LEVEL_GROUP=n: groups of n.
             int group_first = k, group_last = k;
             if (two_streams && max_depth >= 3 && k < max_depth) {
-                const bool groups = tune.tail_levels <= 0 && f.light_waves && (tune.level_group > 0 || grid);
+                const bool groups = tune.tail_levels <= 0 && f.light_waves;
                 const int first = tune.tail_levels > 0 ? std::max(1, max_depth - tune.tail_levels)
                                   : groups             ? std::min(3, max_depth - 2)
                                                        : max_depth - 2;
@@ -2050,12 +2049,7 @@ int enqueue_rows(rt_ctx *ctx, DeviceState &d, const rt_camera *cam, int w, int h
             if (k < group_last) continue;
             if (group_first < group_last) {
                 rtk_plain_levels(d.scene, f, group_first, k, dev_pixels, plain_blocks, where);
-                // (a pair of levels under more than four lights, outside the grid scenes: a launch each, as measured)
-                if (f.light_waves && (k - group_first > 1 || nl <= 4 || grid))
-                    rtk_shade_lights(d.scene, f, group_first, k, f.lit ? 3 : 0, dev_pixels, light_blocks, where);
-                else if (f.light_waves)
-                    for (int lv = group_first; lv <= k; lv++)
-                        rtk_shade_lights(d.scene, f, lv, lv, f.lit ? 3 : 0, dev_pixels, light_blocks, where);
+                if (f.light_waves) rtk_shade_lights(d.scene, f, group_first, k, f.lit ? 3 : 0, dev_pixels, light_blocks, where);
                 continue;
             }
             rtk_trace(d.scene, f, k, false, dev_pixels, plain_blocks, where);
