@@ -79,6 +79,7 @@ CONFIGS = {
                workload="synthetic 64k-sphere scene (65536 spheres + 6 planes, 16 lights), 1920x1080, 8 mirror bounces",
                pmc="r03_c5_trace_pmc.json"),
 }
+STEADY_FRAMES = 300  # frames of the untimed loop behind a short timed loop (`ms_per_frame_of_300_more_frames`)
 WARM_SECONDS = 0.3   # untimed frames before the timed loop run at least this long: the clocks have ramped, whatever --steps
 
 
@@ -228,6 +229,16 @@ def main() -> None:
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    # A short timed loop carries what starting from an idle device costs (the first launch after the fence finds the
+    # queues asleep: ~0.3 ms, i.e. 4 % of twenty 4K frames); the same loop over STEADY_FRAMES frames right behind it,
+    # for the record next to `ms_per_step`, never instead of it.
+    steady_ms = None
+    if args.steps < STEADY_FRAMES:
+        t1 = time.perf_counter()
+        for _ in range(STEADY_FRAMES):
+            step()
+        fence()
+        steady_ms = (time.perf_counter() - t1) * 1e3 / STEADY_FRAMES
 
     # Did the device finish every frame it was given?  (A stalled level schedule leaves a frame
     # incomplete; its time must not be reported.)  Every rank checks, every rank learns the result.
@@ -305,7 +316,7 @@ def main() -> None:
             "plane_tests", "triangle_tests", "filter_ray_tests", "filter_origin_terms", "exact_candidates",
             "primary_filter_ray_tests", "primary_exact_candidates", "shadow_candidates")
     totals = torch.tensor([float(st[k]) for k in keys], dtype=torch.float64, device="cuda")
-    times = torch.tensor([elapsed, ev["trace_ms"], ev["kernel_ms"], ev["primary_ms"], ev["shade_ms"], stalled] +
+    times = torch.tensor([elapsed, ev["trace_ms"], ev["kernel_ms"], ev["primary_ms"], ev["shade_ms"], stalled, steady_ms or 0.0] +
                          list(blocking.values()), dtype=torch.float64, device="cuda")
     if dist is not None:
         if backend != "nccl":   # (host tensors: see FrameGatherer._gather_through_host)
@@ -313,8 +324,8 @@ def main() -> None:
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     tot = dict(zip(keys, totals.tolist()))
-    elapsed, trace_ms, kernel_ms, primary_ms, shade_ms, stalled = times.tolist()[:6]
-    blocking = dict(zip(blocking, (round(v, 4) for v in times.tolist()[6:])))
+    elapsed, trace_ms, kernel_ms, primary_ms, shade_ms, stalled, steady_ms = times.tolist()[:7]
+    blocking = dict(zip(blocking, (round(v, 4) for v in times.tolist()[7:])))
     if stalled:
         for c in contexts:
             c.close()
@@ -362,6 +373,9 @@ def main() -> None:
             "n_gpus": world, "nranks": nranks, "steps": args.steps, "warmup": args.warmup,
             "untimed_frames_before_the_loop": args.warmup + 3 + extra_warm,
             "ms_per_step": round(ms_per_step, 4),
+            # (short loops only: the same loop over 300 more frames right behind the timed one; the timed loop starts from
+            # an idle device, which costs ~0.3 ms whatever the number of steps)
+            "ms_per_frame_of_300_more_frames": round(steady_ms, 4) if steady_ms else None,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
