@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Random small scenes through the library and the CPU restatement, frame for frame: soak.py [cases] [seed].
+"""Random small scenes through the library and the CPU restatement, frame for frame: python tests/soak.py [cases] [seed]
+(a checker like the tests beside it, run by hand: pytest does not collect it).
 One context for all cases (scenes, sizes and depths change under it; every case renders twice, so that the second frame
 runs on the first one's hints).  Prints one line per mismatch and a summary; exit status 1 on any mismatch."""
 import os
@@ -12,8 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raytracer_amd import Camera, Light, RenderContext, synthetic_scene  # noqa: E402
 from oracle import oracle as O  # noqa: E402  (the checker)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-from parity import EXACT_FLOOR, WITHIN1_FLOOR, compare  # noqa: E402
+from tests.parity import EXACT_FLOOR, WITHIN1_FLOOR, compare  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
